@@ -1,0 +1,166 @@
+"""ctypes front end of the CPU oracle (oracle/icp_oracle.c).
+
+TEST INFRASTRUCTURE — not product code.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg import this
+package.  The product modules under ``iterative-closest-point-avmi_amd/`` never
+do, and raise when the HIP library is missing instead of falling back here.
+
+Parity status: pinned.  Every entry point is checked against golden vectors
+captured by running the reference (tests/golden/make_golden.py →
+tests/test_oracle_golden.py).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+
+CONVERGED, MAXITER, FEW_INLIERS = 1, 2, 3
+
+
+def build(force=False):
+    """Compile liboracle.so with gcc (seconds). Safe to call repeatedly."""
+    src = os.path.join(_HERE, "icp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        dp, ip, fp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        L.orc_voxel_downsample.argtypes = [dp, C.c_int, C.c_int, C.c_double, dp]
+        L.orc_voxel_downsample.restype = C.c_int
+        for f in (L.orc_nn_brute, L.orc_nn_kdtree):
+            f.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, ip, dp]
+            f.restype = None
+        L.orc_kd_create.argtypes = [dp, C.c_int, C.c_int]
+        L.orc_kd_create.restype = C.c_void_p
+        L.orc_kd_destroy.argtypes = [C.c_void_p]
+        L.orc_kd_knn.argtypes = [C.c_void_p, dp, C.c_int, C.c_int, ip, dp]
+        L.orc_normals_2d.argtypes = [dp, C.c_int, C.c_int, dp]
+        L.orc_p2l_solve_2d.argtypes = [dp, C.c_int, dp, dp, ip, dp, dp]
+        L.orc_p2p_step.argtypes = [dp, dp, C.c_int, C.c_int, dp, dp]
+        L.orc_icp.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
+                              dp, dp, C.c_int, C.c_int, C.c_double, C.c_int,
+                              dp, dp, dp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_icp.restype = C.c_int
+        L.orc_bresenham.argtypes = [C.c_int64] * 4 + [ip, C.c_int64]
+        L.orc_bresenham.restype = C.c_int64
+        L.orc_world_to_grid.argtypes = [dp, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int64)]
+        L.orc_grid_update_scan.argtypes = [fp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                           C.c_double, C.c_double, dp, C.c_int,
+                                           C.c_double, C.c_double, C.c_double, C.c_double]
+        L.orc_grid_update_scan.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def voxel_downsample(points, voxel_size):
+    p = _d(points)
+    n, dim = p.shape
+    out = np.empty((max(n, 1), dim))
+    nv = lib().orc_voxel_downsample(_p(p), n, dim, float(voxel_size), _p(out))
+    return out[:nv].copy()
+
+
+def nn(src, tgt, kdtree=False):
+    s, t = _d(src), _d(tgt)
+    idx = np.empty(len(s), dtype=np.int32)
+    dist = np.empty(len(s))
+    f = lib().orc_nn_kdtree if kdtree else lib().orc_nn_brute
+    f(_p(s), len(s), _p(t), len(t), s.shape[1], _p(idx, C.c_int32), _p(dist))
+    return dist, idx
+
+
+def knn(pts, queries, k):
+    t, q = _d(pts), _d(queries)
+    h = lib().orc_kd_create(_p(t), len(t), t.shape[1])
+    idx = np.empty((len(q), k), dtype=np.int32)
+    d2 = np.empty((len(q), k))
+    lib().orc_kd_knn(h, _p(q), len(q), k, _p(idx, C.c_int32), _p(d2))
+    lib().orc_kd_destroy(h)
+    return d2, idx
+
+
+def normals_2d(points, k=10):
+    p = _d(points)
+    out = np.zeros_like(p)
+    lib().orc_normals_2d(_p(p), len(p), int(k), _p(out))
+    return out
+
+
+def p2l_solve_2d(source_pts, target_pts, target_normals, nn_indices):
+    s, t, n = _d(source_pts), _d(target_pts), _d(target_normals)
+    idx = np.ascontiguousarray(nn_indices, dtype=np.int32)
+    R, tt = np.empty(4), np.empty(2)
+    lib().orc_p2l_solve_2d(_p(s), len(s), _p(t), _p(n), _p(idx, C.c_int32), _p(R), _p(tt))
+    return R.reshape(2, 2), tt
+
+
+def p2p_step(P, Q):
+    P, Q = _d(P), _d(Q)
+    dim = P.shape[1]
+    r, t = np.empty(dim * dim), np.empty(dim)
+    lib().orc_p2p_step(_p(P), _p(Q), len(P), dim, _p(r), _p(t))
+    return r.reshape(dim, dim), t
+
+
+def icp(source, target, error_threshold, max_iterations, voxel_size, R_init=None, t_init=None,
+        method="point_to_point", normal_k=10, max_corr_dist=None, kdtree=True):
+    """Returns (R, t, error, info) with info = dict(iters, status, delta, n_src, n_tgt)."""
+    s, t = _d(source), _d(target)
+    dim = s.shape[1]
+    R, tt, err, delta = np.empty(dim * dim), np.empty(dim), C.c_double(), C.c_double()
+    iters, ns, nt = C.c_int(), C.c_int(), C.c_int()
+    have = R_init is not None and t_init is not None
+    Ri = _d(R_init) if have else None
+    ti = _d(t_init) if have else None
+    st = lib().orc_icp(_p(s), len(s), _p(t), len(t), dim, float(error_threshold), int(max_iterations),
+                       float(voxel_size), _p(Ri) if have else None, _p(ti) if have else None,
+                       1 if method == "point_to_line" else 0, int(normal_k),
+                       -1.0 if max_corr_dist is None else float(max_corr_dist), 1 if kdtree else 0,
+                       _p(R), _p(tt), C.byref(err), C.byref(iters), C.byref(delta), C.byref(ns), C.byref(nt))
+    info = dict(iters=iters.value, status=st, delta=delta.value, n_src=ns.value, n_tgt=nt.value)
+    return R.reshape(dim, dim), tt, err.value, info
+
+
+def bresenham(x0, y0, x1, y1):
+    n = lib().orc_bresenham(x0, y0, x1, y1, None, 0)
+    cells = np.empty((max(n, 1), 2), dtype=np.int32)
+    lib().orc_bresenham(x0, y0, x1, y1, _p(cells, C.c_int32), n)
+    return cells[:n]
+
+
+def world_to_grid(w, mn, res):
+    w = _d(w)
+    out = np.empty(len(w), dtype=np.int64)
+    lib().orc_world_to_grid(_p(w), len(w), float(mn), float(res), _p(out, C.c_int64))
+    return out
+
+
+def grid_update_scan(log_odds, min_x, min_y, res, origin_xy, hits, l_hit, l_miss, lo, hi):
+    """In-place on a C-contiguous float32 (ny, nx) array. Returns #cell updates."""
+    assert log_odds.dtype == np.float32 and log_odds.flags.c_contiguous
+    h = _d(hits).reshape(-1, 2)
+    ny, nx = log_odds.shape
+    return lib().orc_grid_update_scan(_p(log_odds, C.c_float), ny, nx, float(min_x), float(min_y), float(res),
+                                      float(origin_xy[0]), float(origin_xy[1]), _p(h), len(h),
+                                      float(l_hit), float(l_miss), float(lo), float(hi))
