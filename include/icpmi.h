@@ -1,0 +1,168 @@
+/*
+ * icpmi.h — C ABI of libicpmi.so: the MI355X (gfx950) implementation of the
+ * per-scan hot path of DUBSON0/iterative-closest-point-avmi.
+ *
+ * The reference has no FFI layer: its boundary is the Python module surface of
+ * utilities/icp.py and utilities/mapping.py.  Each entry point below names the
+ * reference function (file:line under /root/reference) it replaces; the Python
+ * modules in iterative-closest-point-avmi_amd/utilities/ bind these with ctypes
+ * and keep the reference signatures.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer (e.g. torch.Tensor.data_ptr()) unless the
+ *    parameter name ends in _host.  Nothing is allocated, freed or retained by
+ *    the library; scratch memory is passed in as a workspace.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*).
+ *  - Return value: ICPMI_OK (0) or a negative ICPMI_ERR_* code; no exceptions
+ *    cross the boundary.  Launch-time HIP errors are reported as ICPMI_ERR_HIP.
+ *  - Point clouds are row-major float64 (n, dim), dim = 2 or 3, like the
+ *    reference's NumPy arrays.  A *cloud set* is several clouds packed in one
+ *    buffer: `off[c]` is the first row of cloud c (C+1 entries, capacity based),
+ *    `cnt[c]` the number of valid rows (device side, so that voxel filtering,
+ *    normals and ICP chain without a host round trip).  cnt == NULL means full
+ *    capacity (off[c+1]-off[c]).
+ */
+#ifndef ICPMI_H
+#define ICPMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICPMI_OK 0
+#define ICPMI_ERR_ARG (-1)        /* bad argument (dim, sizes, null pointer)      */
+#define ICPMI_ERR_WORKSPACE (-2)  /* workspace too small                          */
+#define ICPMI_ERR_HIP (-3)        /* HIP runtime error at launch                  */
+#define ICPMI_ERR_UNSUPPORTED (-4)
+
+/* ICP method, reference utilities/icp.py:133 `method=` */
+#define ICPMI_POINT_TO_POINT 0
+#define ICPMI_POINT_TO_LINE 1
+
+/* per-pair termination status (slot ICPMI_RES_STATUS of a result record) */
+#define ICPMI_ST_CONVERGED 1      /* icp.py:216-219                               */
+#define ICPMI_ST_MAXITER 2        /* icp.py:222-223                               */
+#define ICPMI_ST_FEW_INLIERS 3    /* icp.py:186-187 `break`                       */
+#define ICPMI_ST_EMPTY 4          /* a cloud of the pair is empty after filtering */
+
+/* One ICP result = 16 float64: R row-major in [0, dim*dim), t in [9, 9+dim),
+ * then error, last |prev_error - error|, iterations executed, status.
+ * All-double so that one RCCL all_gather moves a batch of results. */
+#define ICPMI_RES_DOUBLES 16
+#define ICPMI_RES_R 0
+#define ICPMI_RES_T 9
+#define ICPMI_RES_ERR 12
+#define ICPMI_RES_DELTA 13
+#define ICPMI_RES_ITERS 14
+#define ICPMI_RES_STATUS 15
+
+typedef struct icpmi_icp_params {
+    double error_threshold;   /* icp.py:132 */
+    double max_corr_dist;     /* icp.py:134; < 0 means None */
+    int32_t max_iterations;   /* icp.py:132 */
+    int32_t method;           /* ICPMI_POINT_TO_POINT / ICPMI_POINT_TO_LINE */
+    int32_t has_init;         /* 1: R_init AND t_init given (icp.py:153) */
+    int32_t dim;              /* 2 or 3 */
+} icpmi_icp_params;
+
+const char* icpmi_version(void);
+const char* icpmi_strerror(int code);
+
+/* ---- voxel_downsample, utilities/icp.py:117-129 --------------------------
+ * For every cloud c: keys floor((p - min_c) / voxel) per axis, lexicographic
+ * unique, per-voxel mean with the sum taken in input order.  out_pts uses the
+ * same offsets as the input; out_cnt[c] = number of voxels (or -1 if the key
+ * range overflows 64 bits).  off_host mirrors off_dev (the launcher routes
+ * clouds larger than 8192 points to the multi-kernel path). */
+size_t icpmi_voxel_workspace_bytes(int32_t max_n);
+int icpmi_voxel_downsample_batch(const double* pts, const int32_t* off_dev, const int32_t* off_host,
+                                 int32_t n_clouds, int32_t dim, double voxel_size,
+                                 double* out_pts, int32_t* out_cnt,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- nearest neighbour, icp.py:35-46,173,179 (scipy KDTree.query, k=1) ----
+ * Pair b matches every valid row of cloud pair_src[b] against cloud
+ * pair_tgt[b] (exhaustive, LDS-tiled, float64 direct differences, lowest index
+ * on ties).  out_idx/out_dist are [n_pairs][out_stride]; dist is the Euclidean
+ * distance (sqrt), index is relative to the target cloud. */
+int icpmi_nn_batch(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
+                   const int32_t* pair_src, const int32_t* pair_tgt, int32_t n_pairs,
+                   int32_t max_src_n, int32_t dim,
+                   int32_t* out_idx, double* out_dist, int32_t out_stride, void* stream);
+
+/* ---- estimate_normals_2d, icp.py:51-76 ------------------------------------
+ * k+1 nearest neighbours (self included, k clamped to n-1), 2x2 covariance,
+ * eigenvector of the smaller eigenvalue, unit length.  Sign is arbitrary, as
+ * in the reference (it cancels in the point-to-line solve).  k <= 31.
+ * One workgroup per selected cloud: cloud_ids[n_sel] lists the clouds to
+ * process (NULL = clouds 0..n_sel-1).  max_n bounds the rows of any selected
+ * cloud; total_rows = off[C].  The workspace is only needed when max_n > 8192
+ * (the x-sorted index then lives in global memory instead of LDS). */
+size_t icpmi_normals_workspace_bytes(int32_t total_rows, int32_t max_n);
+int icpmi_normals_2d_batch(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
+                           const int32_t* cloud_ids, int32_t n_sel, int32_t total_rows,
+                           int32_t max_n, int32_t k, double* out_normals,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- _point_to_line_solve_2d, icp.py:79-115 --------------------------------
+ * One linearised point-to-line step over n_src correspondences. out_Rt = 6
+ * doubles: R row-major (4) then t (2). Exactly singular system -> identity. */
+int icpmi_p2l_solve_2d(const double* src, int32_t n_src, const double* tgt, const double* normals,
+                       const int32_t* nn_idx, double* out_Rt, void* stream);
+
+/* ---- ICP, icp.py:132-223 (after its two voxel_downsample calls) ------------
+ * Runs n_pairs independent registrations to completion on the device: NN
+ * search, correspondence rejection, point-to-line / point-to-point solve,
+ * apply, error, convergence test; one workgroup per pair, no host round trip.
+ * normals: same row layout as pts (only rows of target clouds are read; may be
+ * NULL for point_to_point).  init: [n_pairs][dim*dim + dim] (R then t) or NULL.
+ * results: [n_pairs][ICPMI_RES_DOUBLES].  max_src_n bounds the valid rows of
+ * any source cloud (sizes the workspace). */
+size_t icpmi_icp_workspace_bytes(int32_t n_pairs, int32_t max_src_n, int32_t dim);
+int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
+                    const double* normals, const int32_t* pair_src, const int32_t* pair_tgt,
+                    int32_t n_pairs, int32_t max_src_n, const icpmi_icp_params* params_host,
+                    const double* init, double* results,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- OccupancyGrid2D, utilities/mapping.py ---------------------------------
+ * world -> cell index, mapping.py:57-60,94-98: floor((w - min) / res), float64
+ * IEEE division, result as int64. */
+int icpmi_world_to_grid(const double* w, int64_t n, double min_w, double resolution,
+                        int64_t* out, void* stream);
+
+/* Cells of _bresenham(x0,y0,x1,y1), mapping.py:68-89 (start included, end
+ * excluded), for n_seg segments {x0,y0,x1,y1} (int32).  Segment s writes its
+ * max(|dx|,|dy|) cells (x,y int32 pairs) at out_cells[2*cell_off[s] ...]. This
+ * is the device function the ray-cast kernel walks; exposed for parity tests
+ * and for the `_bresenham` method of the drop-in class. */
+int icpmi_bresenham_cells(const int32_t* segs, const int64_t* cell_off, int32_t n_seg,
+                          int32_t* out_cells, void* stream);
+
+/* update_scan, mapping.py:103-141, for n_scans consecutive scans (n_scans = 1
+ * is the reference call; more is the _rebuild_map replay of slam.py:271-277).
+ * log_odds: float32 (ny, nx), updated in place.  Scan s has origin
+ * origins[2s..2s+1] and hits rows [hit_off_host[s], hit_off_host[s+1]) of
+ * hits (world frame, float64).  Per cell the result equals the reference's
+ * sequence: H adds of l_hit, then M adds of l_miss, each rounded to float32
+ * from a float64 sum, then one clip to [lo, hi] per scan.
+ * counts: workspace of icpmi_grid_workspace_bytes(ny, nx) bytes, zeroed once
+ * by the caller before first use and owned by this grid afterwards.
+ * scan_seq: number of scans previously applied to this grid with this
+ * workspace (the two bounding-box slots alternate on it).
+ * full_clip != 0 clips every cell of the grid on each scan (needed only when
+ * cells may lie outside [lo, hi] beforehand). */
+size_t icpmi_grid_workspace_bytes(int32_t ny, int32_t nx);
+int icpmi_grid_update_scans(float* log_odds, void* counts, int32_t ny, int32_t nx,
+                            double min_x, double min_y, double resolution,
+                            const double* origins, const double* hits, const int32_t* hit_off_host,
+                            int32_t n_scans, double l_hit, double l_miss, double lo, double hi,
+                            int64_t scan_seq, int32_t full_clip, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICPMI_H */

@@ -1,0 +1,326 @@
+// raycast.hip — K6/K7: OccupancyGrid2D.update_scan (reference utilities/mapping.py:103-141).
+//
+// Reference order per scan: every in-bounds hit cell += l_hit (np.add.at, so
+// duplicates accumulate), then every in-bounds cell of every Bresenham ray
+// += l_miss, then the whole grid is clipped once.  Each += is
+// float32(float64(cell) + l).  All hit adds are equal and all miss adds are
+// equal, so a cell's new value is a function of (old value, H, M) only:
+//   K6 ray_count:    integer atomics count H (high 16 bits) and M (low 16 bits)
+//                    per cell — order independent, hence exact and reproducible;
+//   K7 ray_finalize: walks the bounding box of the scan, and for every counted
+//                    cell replays H + M rounded adds and the clip, then zeroes
+//                    the counter.
+// Float atomics cannot do this: they are order dependent and f32+f32 differs
+// from f32(f64+f64).
+//
+// Bresenham cells (mapping.py:68-89: start included, end excluded,
+// n = max(|dx|,|dy|) cells): cell k lies at major = m0 + sm*k and
+// minor = n0 + sn*((2*k*dmin + dmaj - 1) / (2*dmaj)) — integer division — with
+// the x axis as major when dx >= dy.  A wave covers 64 neighbouring beams at
+// the same 16 steps; inside a chunk the quotient/remainder pair is advanced
+// incrementally, and equal cells in adjacent lanes are merged into one atomic
+// (all 2 048 beams start in the origin cell).
+#include "common.hpp"
+
+namespace icpmi {
+
+constexpr int RC_THREADS = 256;
+constexpr int RC_STEPS = 16;          // Bresenham steps per chunk
+constexpr int RC_SLOTS = 16;          // chunk slots per 64-beam group (grid-stride over longer rays)
+constexpr int RC_COORD_MAX = 1 << 29; // cell coordinates are clamped to +-2^29
+constexpr int RC_FIN_BLOCKS = 1024;
+
+struct GridDesc {
+    int nx, ny;
+    double min_x, min_y, res;
+};
+
+// bounding-box slot: every field grows by atomicMax and 0 means "empty"
+struct BBox {
+    uint32_t inv_x0;   // nx - x0
+    uint32_t inv_y0;   // ny - y0
+    uint32_t x1p;      // x1 + 1
+    uint32_t y1p;      // y1 + 1
+};
+
+__device__ __forceinline__ bool world_to_cell(double w, double mn, double res, int& out) {
+    const double f = floor((w - mn) / res);          // mapping.py:58-59,96-97
+    if (!(fabs(f) < 1e300)) return false;            // NaN / inf: the reference raises on int()
+    out = f > (double)RC_COORD_MAX ? RC_COORD_MAX : (f < -(double)RC_COORD_MAX ? -RC_COORD_MAX : (int)f);
+    return true;
+}
+
+// Walker over the cells of one ray.
+struct Ray {
+    int m0, n0, sm, sn;       // start on major / minor axis, step signs
+    int dmaj, dmin, n;        // |delta| on major / minor axis, number of cells
+    bool xmajor;
+    int q;                    // minor offset at the current step
+    long long rem;            // (2*k*dmin + dmaj - 1) mod (2*dmaj)
+
+    __device__ __forceinline__ void init(int x0, int y0, int x1, int y1) {
+        const int dx = abs(x1 - x0), dy = abs(y1 - y0);
+        const int sx = x0 < x1 ? 1 : -1, sy = y0 < y1 ? 1 : -1;
+        xmajor = dx >= dy;
+        m0 = xmajor ? x0 : y0; n0 = xmajor ? y0 : x0;
+        sm = xmajor ? sx : sy; sn = xmajor ? sy : sx;
+        dmaj = xmajor ? dx : dy; dmin = xmajor ? dy : dx;
+        n = dmaj;
+        q = 0; rem = 0;
+    }
+    // position the walker on step k (k < n, so dmaj >= 1)
+    __device__ __forceinline__ void seek(int k) {
+        const long long num = 2ll * k * dmin + dmaj - 1, den = 2ll * dmaj;
+        long long qq = (long long)floor((double)num / (double)den);   // quotient < 2^30: off by at most one
+        long long r = num - qq * den;
+        while (r < 0) { --qq; r += den; }
+        while (r >= den) { ++qq; r -= den; }
+        q = (int)qq; rem = r;
+    }
+    __device__ __forceinline__ void step() {
+        rem += 2ll * dmin;
+        if (rem >= 2ll * dmaj) { rem -= 2ll * dmaj; ++q; }
+    }
+    __device__ __forceinline__ void cell(int k, int& x, int& y) const {
+        const int mj = m0 + sm * k, mn = n0 + sn * q;
+        x = xmajor ? mj : mn; y = xmajor ? mn : mj;
+    }
+    // steps whose MAJOR coordinate lies inside [0, extent): [klo, khi)
+    __device__ __forceinline__ void clip_major(int extent, int& klo, int& khi) const {
+        if (sm > 0) { klo = max(0, -m0); khi = min(n, extent - m0); }
+        else { klo = max(0, m0 - extent + 1); khi = min(n, m0 + 1); }
+        if (khi < klo) khi = klo;
+    }
+};
+
+// mode bits
+constexpr int RC_DO_HITS = 1, RC_DO_MISS = 2, RC_PACKED = 4;
+
+__global__ __launch_bounds__(RC_THREADS) void ray_count_kernel(
+    GridDesc g, const double* __restrict__ origin, const double* __restrict__ hits, int nb,
+    uint32_t* __restrict__ counts, BBox* bbox, int mode) {
+    const int lane = lane_id();
+    const int gw = (blockIdx.x * RC_THREADS + threadIdx.x) >> 6;        // global wave id
+    const int group = gw / RC_SLOTS, slot = gw % RC_SLOTS;
+    const int beam = group * ICPMI_WAVE + lane;
+    int ox = 0, oy = 0, hx = 0, hy = 0;
+    const bool okx = world_to_cell(origin[0], g.min_x, g.res, ox);
+    const bool oky = world_to_cell(origin[1], g.min_y, g.res, oy);
+    bool valid = okx && oky && beam < nb;
+    if (valid) {
+        const bool a = world_to_cell(hits[2 * (size_t)beam], g.min_x, g.res, hx);
+        const bool b = world_to_cell(hits[2 * (size_t)beam + 1], g.min_y, g.res, hy);
+        valid = a && b;
+    }
+
+    if (slot == 0) {
+        // occupied cell, mapping.py:124-129
+        const bool hit_in = valid && hx >= 0 && hx < g.nx && hy >= 0 && hy < g.ny;
+        if ((mode & RC_DO_HITS) && hit_in)
+            atomicAdd(&counts[(size_t)hy * g.nx + hx], (mode & RC_PACKED) ? 0x10000u : 1u);
+        // bounding box of everything this beam can touch: Bresenham stays inside
+        // the rectangle spanned by its end points
+        int bx0 = max(0, min(ox, hx)), bx1 = min(g.nx - 1, max(ox, hx));
+        int by0 = max(0, min(oy, hy)), by1 = min(g.ny - 1, max(oy, hy));
+        const bool any = valid && bx0 <= bx1 && by0 <= by1;
+        uint32_t a = any ? (uint32_t)(g.nx - bx0) : 0u, b = any ? (uint32_t)(g.ny - by0) : 0u;
+        uint32_t c = any ? (uint32_t)(bx1 + 1) : 0u, d = any ? (uint32_t)(by1 + 1) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a = max(a, (uint32_t)__shfl_xor((int)a, o, ICPMI_WAVE));
+            b = max(b, (uint32_t)__shfl_xor((int)b, o, ICPMI_WAVE));
+            c = max(c, (uint32_t)__shfl_xor((int)c, o, ICPMI_WAVE));
+            d = max(d, (uint32_t)__shfl_xor((int)d, o, ICPMI_WAVE));
+        }
+        if (lane == 0 && a) {
+            atomicMax(&bbox->inv_x0, a); atomicMax(&bbox->inv_y0, b);
+            atomicMax(&bbox->x1p, c); atomicMax(&bbox->y1p, d);
+        }
+    }
+    if (!(mode & RC_DO_MISS)) return;
+
+    // free cells along the ray, mapping.py:135-139
+    Ray ray;
+    ray.init(ox, oy, hx, hy);
+    int klo = 0, khi = 0;
+    if (valid) ray.clip_major(ray.xmajor ? g.nx : g.ny, klo, khi);
+    const int len = khi - klo;
+    int lmax = len;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o, ICPMI_WAVE));
+    const int minor_extent = ray.xmajor ? g.ny : g.nx;
+    for (int c0 = slot * RC_STEPS; c0 < lmax; c0 += RC_SLOTS * RC_STEPS) {      // wave-uniform trip count
+        const bool live = c0 < len;
+        if (live) ray.seek(klo + c0);
+#pragma unroll 4
+        for (int i = 0; i < RC_STEPS; ++i) {
+            const int k = klo + c0 + i;
+            long long cellid = -1;
+            if (live && k < khi) {
+                const int mn = ray.n0 + ray.sn * ray.q;
+                if (mn >= 0 && mn < minor_extent) {
+                    int x, y;
+                    ray.cell(k, x, y);
+                    cellid = (long long)y * g.nx + x;
+                }
+                ray.step();
+            }
+            // merge runs of equal cells in adjacent lanes into one atomic
+            const long long prev = __shfl_up(cellid, 1, ICPMI_WAVE);
+            const bool leader = lane == 0 || cellid != prev;
+            const unsigned long long lead = __ballot(leader);
+            if (leader && cellid >= 0) {
+                const unsigned long long above = lane == 63 ? 0ull : (lead >> (lane + 1));
+                const int run = above ? __ffsll((long long)above) : 64 - lane;
+                atomicAdd(&counts[cellid], (uint32_t)run);
+            }
+        }
+    }
+}
+
+// float32(float64(v) + l) repeated H then M times, then the per-scan clip.
+__device__ __forceinline__ float apply_counts(float v0, uint32_t H, uint32_t M, double l_hit, double l_miss,
+                                              float lo32, float hi32, bool clip) {
+    if (clip) {
+        // Saturated far beyond a clamp?  Every rounded add is within half an ulp of
+        // the exact one, so |v_final - exact| <= (H+M) * ulp(vmax)/2 < bound.
+        const double exact = (double)v0 + (double)H * l_hit + (double)M * l_miss;
+        const double vmax = fabs((double)v0) + (double)H * fabs(l_hit) + (double)M * fabs(l_miss);
+        const double bound = ((double)H + (double)M) * vmax * 1.2e-7 + 1e-30;
+        if (exact + bound < (double)lo32) return lo32;
+        if (exact - bound > (double)hi32) return hi32;
+    }
+    float v = v0;
+    for (uint32_t i = 0; i < H; ++i) {
+        const float nv = (float)((double)v + l_hit);
+        if (nv == v) break;                       // fixed point: further equal adds change nothing
+        v = nv;
+    }
+    for (uint32_t i = 0; i < M; ++i) {
+        const float nv = (float)((double)v + l_miss);
+        if (nv == v) break;
+        v = nv;
+    }
+    if (clip) {                                    // np.clip on float32, mapping.py:141
+        if (v < lo32) v = lo32;
+        if (v > hi32) v = hi32;
+    }
+    return v;
+}
+
+// count_kind: 0 = packed (H<<16 | M), 1 = counts are hits, 2 = counts are misses
+__global__ __launch_bounds__(RC_THREADS) void ray_finalize_kernel(
+    GridDesc g, float* __restrict__ log_odds, uint32_t* __restrict__ counts, const BBox* bbox, BBox* other,
+    double l_hit, double l_miss, float lo32, float hi32, int count_kind, int clip, int full_clip) {
+    int x0, y0, x1, y1;
+    const BBox bb = *bbox;
+    if (full_clip) { x0 = 0; y0 = 0; x1 = g.nx - 1; y1 = g.ny - 1; }
+    else {
+        if (bb.inv_x0 == 0) { x0 = 0; y0 = 0; x1 = -1; y1 = -1; }
+        else { x0 = g.nx - (int)bb.inv_x0; y0 = g.ny - (int)bb.inv_y0; x1 = (int)bb.x1p - 1; y1 = (int)bb.y1p - 1; }
+    }
+    for (int y = y0 + blockIdx.x; y <= y1; y += gridDim.x)
+        for (int x = x0 + threadIdx.x; x <= x1; x += RC_THREADS) {
+            const size_t c = (size_t)y * g.nx + x;
+            const uint32_t cn = counts[c];
+            if (cn) {
+                counts[c] = 0;
+                const uint32_t H = count_kind == 0 ? cn >> 16 : (count_kind == 1 ? cn : 0u);
+                const uint32_t M = count_kind == 0 ? cn & 0xffffu : (count_kind == 2 ? cn : 0u);
+                log_odds[c] = apply_counts(log_odds[c], H, M, l_hit, l_miss, lo32, hi32, clip != 0);
+            } else if (full_clip && clip) {
+                float v = log_odds[c];
+                if (v < lo32) v = lo32;
+                if (v > hi32) v = hi32;
+                log_odds[c] = v;
+            }
+        }
+    if (other && blockIdx.x == 0 && threadIdx.x == 0) { other->inv_x0 = 0; other->inv_y0 = 0; other->x1p = 0; other->y1p = 0; }
+}
+
+__global__ void world_to_grid_kernel(const double* __restrict__ w, long long n, double mn, double res, long long* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (long long)floor((w[i] - mn) / res);
+}
+
+// One thread per segment, walking in chunks exactly like ray_count_kernel.
+__global__ void bresenham_cells_kernel(const int32_t* __restrict__ segs, const long long* __restrict__ cell_off, int n_seg,
+                                       int32_t* __restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_seg) return;
+    Ray ray;
+    ray.init(segs[4 * s], segs[4 * s + 1], segs[4 * s + 2], segs[4 * s + 3]);
+    int32_t* o = out + 2 * cell_off[s];
+    for (int c0 = 0; c0 < ray.n; c0 += RC_STEPS) {
+        ray.seek(c0);
+        for (int i = 0; i < RC_STEPS && c0 + i < ray.n; ++i) {
+            int x, y;
+            ray.cell(c0 + i, x, y);
+            o[2 * (size_t)(c0 + i)] = x; o[2 * (size_t)(c0 + i) + 1] = y;
+            ray.step();
+        }
+    }
+}
+
+}  // namespace icpmi
+
+extern "C" size_t icpmi_grid_workspace_bytes(int32_t ny, int32_t nx) {
+    if (ny <= 0 || nx <= 0) return 0;
+    return (size_t)ny * (size_t)nx * sizeof(uint32_t) + 256;
+}
+
+extern "C" int icpmi_world_to_grid(const double* w, int64_t n, double min_w, double resolution, int64_t* out, void* stream) {
+    if (!w || !out || n < 0) return ICPMI_ERR_ARG;
+    if (n == 0) return ICPMI_OK;
+    icpmi::world_to_grid_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(w, (long long)n, min_w, resolution, (long long*)out);
+    ICPMI_LAUNCH_CHECK();
+    return ICPMI_OK;
+}
+
+extern "C" int icpmi_bresenham_cells(const int32_t* segs, const int64_t* cell_off, int32_t n_seg, int32_t* out_cells, void* stream) {
+    if (!segs || !cell_off || !out_cells || n_seg < 0) return ICPMI_ERR_ARG;
+    if (n_seg == 0) return ICPMI_OK;
+    icpmi::bresenham_cells_kernel<<<(n_seg + 63) / 64, 64, 0, (hipStream_t)stream>>>(segs, (const long long*)cell_off, n_seg, out_cells);
+    ICPMI_LAUNCH_CHECK();
+    return ICPMI_OK;
+}
+
+extern "C" int icpmi_grid_update_scans(float* log_odds, void* counts_ws, int32_t ny, int32_t nx,
+                                       double min_x, double min_y, double resolution,
+                                       const double* origins, const double* hits, const int32_t* hit_off_host,
+                                       int32_t n_scans, double l_hit, double l_miss, double lo, double hi,
+                                       int64_t scan_seq, int32_t full_clip, void* stream) {
+    using namespace icpmi;
+    if (!log_odds || !counts_ws || !origins || !hit_off_host || ny <= 0 || nx <= 0 || n_scans < 0) return ICPMI_ERR_ARG;
+    if (ny > RC_COORD_MAX || nx > RC_COORD_MAX || !(resolution > 0.0)) return ICPMI_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* counts = (uint32_t*)counts_ws;
+    BBox* slots = (BBox*)((unsigned char*)counts_ws + (size_t)ny * (size_t)nx * sizeof(uint32_t));
+    GridDesc g{nx, ny, min_x, min_y, resolution};
+    const float lo32 = (float)lo, hi32 = (float)hi;
+    for (int s = 0; s < n_scans; ++s) {
+        const int nb = hit_off_host[s + 1] - hit_off_host[s];
+        if (nb < 0) return ICPMI_ERR_ARG;
+        if (nb == 0) continue;                                  // mapping.py:113-114: silent no-op, no clip
+        if (!hits) return ICPMI_ERR_ARG;
+        const double* h = hits + 2 * (size_t)hit_off_host[s];
+        const double* o = origins + 2 * (size_t)s;
+        BBox* cur = slots + ((scan_seq + s) & 1);
+        BBox* oth = slots + ((scan_seq + s + 1) & 1);
+        const int groups = (nb + ICPMI_WAVE - 1) / ICPMI_WAVE;
+        const long waves = (long)groups * RC_SLOTS;
+        const unsigned blocks = (unsigned)((waves * ICPMI_WAVE + RC_THREADS - 1) / RC_THREADS);
+        if (nb <= 65535) {
+            ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, RC_DO_HITS | RC_DO_MISS | RC_PACKED);
+            ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, log_odds, counts, cur, oth, l_hit, l_miss, lo32, hi32, 0, 1, full_clip);
+        } else {
+            // more beams than a 16-bit counter holds: hits and misses in two rounds
+            ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, RC_DO_HITS);
+            ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, log_odds, counts, cur, nullptr, l_hit, l_miss, lo32, hi32, 1, 0, 0);
+            ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, RC_DO_MISS);
+            ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, log_odds, counts, cur, oth, l_hit, l_miss, lo32, hi32, 2, 1, full_clip);
+        }
+        ICPMI_LAUNCH_CHECK();
+    }
+    return ICPMI_OK;
+}

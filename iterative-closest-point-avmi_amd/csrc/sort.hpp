@@ -1,0 +1,36 @@
+// sort.hpp — workgroup-wide bitonic sort of (key, row) pairs held in LDS.
+#pragma once
+#include "common.hpp"
+
+namespace icpmi {
+
+// Sorts npad (power of two) pairs ascending by (key, row).  Rows are unique, so
+// the order is total and equals a stable sort by key.  Pad with key = ~0,
+// row = ~0.  Ends with a barrier.
+__device__ __forceinline__ void bitonic_sort_pairs(uint64_t* keys, uint32_t* rows, int npad) {
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = threadIdx.x; p < npad / 2; p += blockDim.x) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int x = i | j;
+                const uint64_t ka = keys[i], kb = keys[x];
+                const uint32_t ra = rows[i], rb = rows[x];
+                const bool gt = ka > kb || (ka == kb && ra > rb);
+                const bool asc = (i & k) == 0;
+                if (gt == asc) { keys[i] = kb; keys[x] = ka; rows[i] = rb; rows[x] = ra; }
+            }
+            __syncthreads();
+        }
+}
+
+// Order-preserving map double -> uint64 (and back): a < b  <=>  enc(a) < enc(b).
+__device__ __forceinline__ uint64_t f64_sortable(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_unsortable(uint64_t k) {
+    const uint64_t b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+}  // namespace icpmi

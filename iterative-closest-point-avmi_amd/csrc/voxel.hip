@@ -1,0 +1,278 @@
+// voxel.hip — K5: voxel_downsample (reference utilities/icp.py:117-129).
+//
+// Reference semantics reproduced exactly:
+//   min_bound = points.min(0)                      per cloud, per call
+//   key       = floor((p - min_bound) / voxel)     float64 IEEE divide, per axis
+//   rows      = np.unique(keys, axis=0)            lexicographic order of the keys
+//   mean      = bincount(weights=p) / bincount     sum taken in INPUT order
+// A stable sort by the linearised key ((k0*E1 + k1)*E2 + k2, E = key extent per
+// axis) followed by an in-order per-voxel sum gives bit-identical output.
+//
+// Clouds of <= 8192 points (every scan) take a single-workgroup path: keys and
+// row ids live in LDS, bitonic sort on (key, row) pairs, one launch for a whole
+// batch of clouds.  Larger clouds (the ~82k-point rolling submap of
+// slam.py:103-108) use rocPRIM's radix sort on the same keys.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "sort.hpp"
+
+namespace icpmi {
+
+constexpr int VOX_THREADS = 1024;
+constexpr int VOX_MAXW = VOX_THREADS / ICPMI_WAVE;
+constexpr int VOX_SMALL_MAX = 8192;
+
+struct VoxHeader {          // big path: written by vox_bounds_kernel
+    double mn[3];
+    double ext[3];          // key extent per axis (as double), 1 for unused axes
+    int32_t overflow;
+};
+
+__device__ __forceinline__ uint64_t vox_key(const double* p, int dim, const double* mn, const double* ext, double voxel) {
+    // floor((p - min) / voxel).astype(int), linearised so that integer order ==
+    // lexicographic order of the per-axis keys
+    uint64_t k = 0;
+    for (int d = 0; d < dim; ++d) {
+        const int64_t kd = (int64_t)floor((p[d] - mn[d]) / voxel);
+        k = k * (uint64_t)ext[d] + (uint64_t)kd;
+    }
+    return k;
+}
+
+// min / max over the rows of one cloud, result in every thread
+template <int DIM>
+__device__ __forceinline__ void cloud_bounds(const double* pts, int n, double (&mn)[3], double (&mx)[3], double* scratch) {
+    for (int d = 0; d < 3; ++d) { mn[d] = __builtin_inf(); mx[d] = -__builtin_inf(); }
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            const double v = pts[(size_t)i * DIM + d];
+            mn[d] = fmin(mn[d], v);
+            mx[d] = fmax(mx[d], v);
+        }
+    const int w = wave_id(), l = lane_id(), nw = blockDim.x / ICPMI_WAVE;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    __syncthreads();
+    if (l == 0)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) { scratch[d * VOX_MAXW + w] = mn[d]; scratch[(3 + d) * VOX_MAXW + w] = mx[d]; }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        double a = __builtin_inf(), b = -__builtin_inf();
+        for (int k = 0; k < nw; ++k) { a = fmin(a, scratch[d * VOX_MAXW + k]); b = fmax(b, scratch[(3 + d) * VOX_MAXW + k]); }
+        mn[d] = a; mx[d] = b;
+    }
+}
+
+// key extents; returns false when the linear key would not fit in 63 bits
+template <int DIM>
+__device__ __forceinline__ bool key_extents(const double (&mn)[3], const double (&mx)[3], double voxel, double (&ext)[3]) {
+    double prod = 1.0;
+    bool ok = true;
+    for (int d = 0; d < 3; ++d) ext[d] = 1.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        const double e = floor((mx[d] - mn[d]) / voxel) + 1.0;
+        if (!(e >= 1.0) || !(e < 9.0e18)) ok = false;
+        ext[d] = e;
+        prod *= e;
+    }
+    return ok && prod < 9.0e18;
+}
+
+// Exclusive prefix sum of one int per thread over the workgroup; `total` gets
+// the grand total.  scratch: VOX_MAXW ints of LDS.
+__device__ __forceinline__ int block_exscan(int v, int* scratch, int& total) {
+    const int l = lane_id(), w = wave_id(), nw = blockDim.x / ICPMI_WAVE;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < ICPMI_WAVE; o <<= 1) {
+        const int t = __shfl_up(inc, o, ICPMI_WAVE);
+        if (l >= o) inc += t;
+    }
+    __syncthreads();
+    if (l == ICPMI_WAVE - 1) scratch[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int k = 0; k < nw; ++k) { const int s = scratch[k]; if (k < w) base += s; tot += s; }
+    total = tot;
+    return base + inc - v;
+}
+
+// After the sort: voxel boundaries, voxel ids, in-order sums, means.
+// keys/rows are sorted by (key, row); thread t owns sorted positions
+// [t*ipt, (t+1)*ipt).  Works on LDS or global arrays (generic pointers).
+template <int DIM>
+__device__ __forceinline__ void voxel_finish(const uint64_t* keys, const uint32_t* rows, int n,
+                                             const double* __restrict__ pts, double* __restrict__ out,
+                                             int32_t* out_cnt, int* iscratch) {
+    const int ipt = (n + blockDim.x - 1) / blockDim.x;
+    const int lo = min(n, (int)threadIdx.x * ipt), hi = min(n, lo + ipt);
+    int heads = 0;
+    for (int r = lo; r < hi; ++r) heads += (r == 0 || keys[r] != keys[r - 1]);
+    int total;
+    int vid = block_exscan(heads, iscratch, total);
+    for (int r = lo; r < hi; ++r) {
+        if (!(r == 0 || keys[r] != keys[r - 1])) continue;
+        const uint64_t k = keys[r];
+        double s[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) s[d] = 0.0;
+        int q = r;
+        for (; q < n && keys[q] == k; ++q) {                 // rows ascending == input order
+            const double* p = pts + (size_t)rows[q] * DIM;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) s[d] += p[d];
+        }
+        const double c = (double)(q - r);
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) out[(size_t)vid * DIM + d] = s[d] / c;
+        ++vid;
+    }
+    if (threadIdx.x == 0) *out_cnt = total;
+}
+
+// ── small path: one workgroup per cloud, everything in LDS ─────────────────
+template <int DIM>
+__global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
+    const double* __restrict__ pts, const int32_t* __restrict__ off, double voxel,
+    double* __restrict__ out_pts, int32_t* __restrict__ out_cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    __shared__ double dscratch[6 * VOX_MAXW];
+    __shared__ int iscratch[VOX_MAXW];
+    const int c = blockIdx.x;
+    const int n = off[c + 1] - off[c];
+    if (n > VOX_SMALL_MAX) return;                            // routed to the big path by the host
+    if (n <= 0) { if (threadIdx.x == 0) out_cnt[c] = 0; return; }
+    const double* P = pts + (size_t)off[c] * DIM;
+    double* O = out_pts + (size_t)off[c] * DIM;
+    int npad = 64;
+    while (npad < n) npad <<= 1;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(dyn);
+    uint32_t* rows = reinterpret_cast<uint32_t*>(dyn + (size_t)npad * sizeof(uint64_t));
+
+    double mn[3], mx[3], ext[3];
+    cloud_bounds<DIM>(P, n, mn, mx, dscratch);
+    if (!key_extents<DIM>(mn, mx, voxel, ext)) { if (threadIdx.x == 0) out_cnt[c] = -1; return; }
+    for (int i = threadIdx.x; i < npad; i += VOX_THREADS) {
+        keys[i] = i < n ? vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel) : ~0ull;
+        rows[i] = i < n ? (uint32_t)i : 0xffffffffu;
+    }
+    __syncthreads();
+    bitonic_sort_pairs(keys, rows, npad);     // == stable sort by key (rows are unique)
+    voxel_finish<DIM>(keys, rows, n, P, O, out_cnt + c, iscratch);
+}
+
+// ── big path ────────────────────────────────────────────────────────────────
+template <int DIM>
+__global__ __launch_bounds__(VOX_THREADS) void vox_bounds_kernel(const double* __restrict__ P, int n, double voxel, VoxHeader* h) {
+    __shared__ double dscratch[6 * VOX_MAXW];
+    double mn[3], mx[3], ext[3];
+    cloud_bounds<DIM>(P, n, mn, mx, dscratch);
+    const bool ok = key_extents<DIM>(mn, mx, voxel, ext);
+    if (threadIdx.x == 0) {
+        for (int d = 0; d < 3; ++d) { h->mn[d] = mn[d]; h->ext[d] = ext[d]; }
+        h->overflow = ok ? 0 : 1;
+    }
+}
+
+template <int DIM>
+__global__ void vox_keys_kernel(const double* __restrict__ P, int n, double voxel, const VoxHeader* __restrict__ h,
+                                uint64_t* __restrict__ keys, uint32_t* __restrict__ rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double mn[3] = {h->mn[0], h->mn[1], h->mn[2]}, ext[3] = {h->ext[0], h->ext[1], h->ext[2]};
+    keys[i] = h->overflow ? 0ull : vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel);
+    rows[i] = (uint32_t)i;
+}
+
+template <int DIM>
+__global__ __launch_bounds__(VOX_THREADS) void vox_finish_kernel(const uint64_t* keys, const uint32_t* rows, int n,
+                                                                 const double* __restrict__ P, double* __restrict__ O,
+                                                                 int32_t* out_cnt, const VoxHeader* __restrict__ h) {
+    __shared__ int iscratch[VOX_MAXW];
+    if (h->overflow) { if (threadIdx.x == 0) *out_cnt = -1; return; }
+    voxel_finish<DIM>(keys, rows, n, P, O, out_cnt, iscratch);
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t radix_temp_bytes(int n) {
+    size_t bytes = 0;
+    uint64_t* k = nullptr;
+    uint32_t* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0, 64, (hipStream_t)0, false);
+    return bytes;
+}
+
+template <int DIM>
+static int voxel_big(const double* P, int n, double voxel, double* O, int32_t* out_cnt, void* ws, size_t ws_bytes, hipStream_t st) {
+    unsigned char* base = (unsigned char*)ws;
+    size_t o = 0;
+    VoxHeader* h = (VoxHeader*)(base + o); o += 256;
+    uint64_t* k0 = (uint64_t*)(base + o); o += align256((size_t)n * 8);
+    uint64_t* k1 = (uint64_t*)(base + o); o += align256((size_t)n * 8);
+    uint32_t* r0 = (uint32_t*)(base + o); o += align256((size_t)n * 4);
+    uint32_t* r1 = (uint32_t*)(base + o); o += align256((size_t)n * 4);
+    size_t tb = radix_temp_bytes(n);
+    if (o + tb > ws_bytes) return ICPMI_ERR_WORKSPACE;
+    vox_bounds_kernel<DIM><<<1, VOX_THREADS, 0, st>>>(P, n, voxel, h);
+    vox_keys_kernel<DIM><<<(n + 255) / 256, 256, 0, st>>>(P, n, voxel, h, k0, r0);
+    if (rocprim::radix_sort_pairs(base + o, tb, k0, k1, r0, r1, (size_t)n, 0, 64, st, false) != hipSuccess) return ICPMI_ERR_HIP;
+    vox_finish_kernel<DIM><<<1, VOX_THREADS, 0, st>>>(k1, r1, n, P, O, out_cnt, h);
+    ICPMI_LAUNCH_CHECK();
+    return ICPMI_OK;
+}
+
+}  // namespace icpmi
+
+extern "C" size_t icpmi_voxel_workspace_bytes(int32_t max_n) {
+    using namespace icpmi;
+    if (max_n <= VOX_SMALL_MAX) return 256;
+    return 256 + 2 * align256((size_t)max_n * 8) + 2 * align256((size_t)max_n * 4) + align256(radix_temp_bytes(max_n)) + 256;
+}
+
+extern "C" int icpmi_voxel_downsample_batch(const double* pts, const int32_t* off_dev, const int32_t* off_host,
+                                            int32_t n_clouds, int32_t dim, double voxel_size,
+                                            double* out_pts, int32_t* out_cnt, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+    using namespace icpmi;
+    if (!pts || !off_dev || !off_host || !out_pts || !out_cnt) return ICPMI_ERR_ARG;
+    if (n_clouds < 0 || (dim != 2 && dim != 3) || !(voxel_size > 0.0)) return ICPMI_ERR_ARG;
+    if (n_clouds == 0) return ICPMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int max_small = 0, n_big = 0;
+    for (int c = 0; c < n_clouds; ++c) {
+        const int n = off_host[c + 1] - off_host[c];
+        if (n < 0) return ICPMI_ERR_ARG;
+        if (n <= VOX_SMALL_MAX) max_small = n > max_small ? n : max_small; else ++n_big;
+    }
+    if (n_big < n_clouds) {
+        int npad = 64;
+        while (npad < max_small) npad <<= 1;
+        const size_t lds = (size_t)npad * 12;
+        if (dim == 2) {
+            if (hipFuncSetAttribute((const void*)voxel_small_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP;
+            voxel_small_kernel<2><<<n_clouds, VOX_THREADS, lds, st>>>(pts, off_dev, voxel_size, out_pts, out_cnt);
+        } else {
+            if (hipFuncSetAttribute((const void*)voxel_small_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP;
+            voxel_small_kernel<3><<<n_clouds, VOX_THREADS, lds, st>>>(pts, off_dev, voxel_size, out_pts, out_cnt);
+        }
+        ICPMI_LAUNCH_CHECK();
+    }
+    for (int c = 0; c < n_clouds && n_big > 0; ++c) {
+        const int n = off_host[c + 1] - off_host[c];
+        if (n <= VOX_SMALL_MAX) continue;
+        if (!workspace) return ICPMI_ERR_WORKSPACE;
+        const double* P = pts + (size_t)off_host[c] * dim;
+        double* O = out_pts + (size_t)off_host[c] * dim;
+        const int rc = dim == 2 ? voxel_big<2>(P, n, voxel_size, O, out_cnt + c, workspace, workspace_bytes, st)
+                                : voxel_big<3>(P, n, voxel_size, O, out_cnt + c, workspace, workspace_bytes, st);
+        if (rc != ICPMI_OK) return rc;
+    }
+    return ICPMI_OK;
+}

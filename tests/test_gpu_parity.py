@@ -1,0 +1,319 @@
+"""GPU parity tests: the HIP path (through the C ABI of libicpmi.so) against the
+CPU oracle and the golden vectors captured from the reference.
+
+Bars: bit-exact for voxel keys/means, NN indices and distances, Bresenham cell
+indices and log-odds cells; <= 1e-5 Frobenius on ICP transforms (BASELINE
+north_star) — the tests hold 1e-9, with iteration counts equal.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_golden, rot_err
+from test_oracle_golden import ICP_CASES, icp_case_args, _grid_shape
+
+pytestmark = pytest.mark.gpu
+
+FRO_TOL = 1e-9        # the contract is 1e-5
+
+
+@pytest.fixture(scope="module")
+def uicp():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    from utilities import icp
+    icp.VERBOSE = False
+    return icp
+
+
+@pytest.fixture(scope="module")
+def umap(uicp):
+    from utilities import mapping
+    return mapping
+
+
+# ── voxel_downsample ────────────────────────────────────────────────────────
+def test_voxel_golden_bit_exact(uicp):
+    z = load_golden("voxel")
+    for name in z["names"]:
+        out = uicp.voxel_downsample(z[f"{name}__in"], float(z[f"{name}__voxel"]))
+        assert out.shape == z[f"{name}__out"].shape, name
+        assert np.array_equal(out, z[f"{name}__out"]), name
+
+
+def test_voxel_submap_radix_path(uicp):
+    """81 920 points -> the rocPRIM path (slam.py:103-108 _build_submap)."""
+    from icpmi import synth
+    z = load_golden("submap_build")
+    segs = synth.maze_segments()
+    poses = synth.trajectory(40)
+    allpts = np.vstack([synth.to_world(synth.scan(p, 500 + i, segs=segs), p) for i, p in enumerate(poses)])
+    assert np.array_equal(uicp.voxel_downsample(allpts, 0.04), z["out"])
+    # around the 8192-point switch between the two paths
+    for n in (8191, 8192, 8193, 20000):
+        assert np.array_equal(uicp.voxel_downsample(allpts[:n], 0.1), oracle.voxel_downsample(allpts[:n], 0.1)), n
+
+
+def test_voxel_batch_and_edges(uicp):
+    from icpmi import batch
+    rng = np.random.default_rng(0)
+    clouds = [rng.normal(size=(n, 2)) * 3 for n in (1, 2, 63, 64, 65, 1000, 2048, 4097, 8192)]
+    clouds.append(np.zeros((50, 2)))                      # every point identical
+    clouds.append(np.empty((0, 2)))                       # empty cloud in a set: count 0
+    cs = batch.CloudSet.from_numpy(clouds)
+    out = batch.voxel_downsample_set(cs, 0.25).to_numpy()
+    for c, o in zip(clouds, out):
+        assert np.array_equal(o, oracle.voxel_downsample(c, 0.25)), len(c)
+    with pytest.raises(ValueError):
+        uicp.voxel_downsample(np.empty((0, 2)), 0.1)     # icp.py:119 raises on empty input
+    t3 = rng.normal(size=(3000, 3))
+    assert np.array_equal(uicp.voxel_downsample(t3, 0.2), oracle.voxel_downsample(t3, 0.2))
+
+
+# ── nearest neighbour ───────────────────────────────────────────────────────
+@pytest.mark.parametrize("case", ["vox", "raw", "submap"])
+def test_nn_golden_exact(uicp, case):
+    z = load_golden("nn")
+    d, i = uicp.nearest_neighbors(z[f"{case}__src"], z[f"{case}__tgt"])
+    assert np.array_equal(i, z[f"{case}__idx"])
+    assert np.array_equal(d, z[f"{case}__dist"])
+
+
+def test_nn_helpers_and_ragged_batch(uicp):
+    from icpmi import batch
+    z = load_golden("nn")
+    assert np.array_equal(uicp.find_nearest_neighbors(z["vox__src"], z["vox__tgt"]), z["helper_nearest"])
+    assert np.array_equal(uicp.find_nearest_neighbor_indices(z["vox__src"], z["vox__tgt"]), z["helper_idx"])
+    assert np.array_equal(uicp.center_of_mass(z["vox__src"]), z["helper_com"])
+    rng = np.random.default_rng(1)
+    sizes = [(1, 1), (5, 3), (300, 2049), (1025, 17), (2048, 2048), (700, 5000)]
+    clouds, ps, pt = [], [], []
+    for n, m in sizes:
+        ps.append(len(clouds)); clouds.append(rng.uniform(-5, 5, size=(n, 2)))
+        pt.append(len(clouds)); clouds.append(rng.uniform(-5, 5, size=(m, 2)))
+    cs = batch.CloudSet.from_numpy(clouds)
+    dist, idx = batch.nn_set(cs, ps, pt)
+    dist, idx = dist.cpu().numpy(), idx.cpu().numpy()
+    for b, (n, m) in enumerate(sizes):
+        do, io = oracle.nn(clouds[ps[b]], clouds[pt[b]])
+        assert np.array_equal(idx[b, :n], io) and np.array_equal(dist[b, :n], do), (n, m)
+    # exact ties: lowest index wins, 3-D works too
+    tgt = np.array([[1.0, 0.0], [-1.0, 0.0], [0.0, 1.0], [0.0, -1.0], [1.0, 0.0]])
+    d, i = uicp.nearest_neighbors(np.zeros((3, 2)), tgt)
+    assert np.array_equal(i, [0, 0, 0]) and np.array_equal(d, [1.0, 1.0, 1.0])
+    s3, t3 = rng.normal(size=(500, 3)), rng.normal(size=(1500, 3))
+    d, i = uicp.nearest_neighbors(s3, t3)
+    do, io = oracle.nn(s3, t3)
+    assert np.array_equal(i, io) and np.array_equal(d, do)
+
+
+# ── normals ─────────────────────────────────────────────────────────────────
+@pytest.mark.parametrize("case", ["tgt_k12", "tgt_k5", "five_k10", "collinear_k8", "diag_k6"])
+def test_normals_golden(uicp, case):
+    z = load_golden("normals")
+    pts, k = z[f"{case}__in"], int(z[f"{case}__k"])
+    n = uicp.estimate_normals_2d(pts, k)
+    assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-12)
+    dots = np.abs(np.sum(n * z[f"{case}__out"], axis=1))
+    assert np.quantile(dots, 0.01) > 1 - 1e-9 and dots.min() > 1 - 1e-6
+    # against the oracle the neighbour sets and the summation order are identical
+    no = oracle.normals_2d(pts, k)
+    assert np.abs(np.abs(np.sum(n * no, axis=1)) - 1).max() < 1e-12
+
+
+def test_normals_sizes(uicp):
+    rng = np.random.default_rng(2)
+    for m, k in ((1, 10), (2, 10), (3, 1), (64, 7), (65, 15), (513, 31), (3000, 12)):
+        pts = rng.uniform(-4, 4, size=(m, 2))
+        n, no = uicp.estimate_normals_2d(pts, k), oracle.normals_2d(pts, k)
+        assert np.abs(np.abs(np.sum(n * no, axis=1)) - 1).max() < 1e-9, (m, k)
+
+
+def test_p2l_solve(uicp):
+    z = load_golden("p2l_solve")
+    R, t = uicp._point_to_line_solve_2d(z["src"], z["tgt"], z["normals"], z["idx"])
+    assert rot_err(R, t, z["R"], z["t"]) < 1e-11
+    R, t = uicp._point_to_line_solve_2d(z["src"], z["tgt"], z["zero_normals"], z["idx"])
+    assert np.array_equal(R, np.eye(2)) and np.array_equal(t, np.zeros(2))      # icp.py:107-108
+
+
+# ── full ICP ────────────────────────────────────────────────────────────────
+@pytest.mark.parametrize("name", list(ICP_CASES))
+def test_icp_golden(uicp, name):
+    z = load_golden("icp")
+    s, t, args = icp_case_args(z, name)
+    R, tt, err = uicp.ICP(s, t, **args)
+    assert rot_err(R, tt, z[f"{name}__R"], z[f"{name}__t"]) < FRO_TOL
+    assert abs(err - float(z[f"{name}__err"])) <= 1e-11 * max(1.0, abs(err))
+    info = uicp.last_icp_info
+    if int(z[f"{name}__conv"]):
+        assert info["status"] == oracle.CONVERGED and info["iterations"] == int(z[f"{name}__iters"])
+    else:
+        Ro, to, eo, io = oracle.icp(s, t, **args)
+        assert info["status"] == io["status"] and info["iterations"] == io["iters"]
+
+
+def test_icp_break_and_prints(uicp, capsys):
+    z = load_golden("icp")
+    a, b = z["scan_a"], z["scan_b"]
+    uicp.VERBOSE = True
+    try:
+        R, t, err = uicp.ICP(a, b + np.array([30.0, 0.0]), 1e-10, 150, 0.04, method="point_to_point", max_corr_dist=0.05)
+        out = capsys.readouterr().out
+        assert "ICP max iterations reached: iter=150, error=inf" in out
+        assert np.isinf(err) and np.array_equal(R, np.eye(2)) and np.array_equal(t, np.zeros(2))
+        assert uicp.last_icp_info["iterations"] == 0
+        uicp.ICP(a, b, 1e-10, 150, 0.04, method="point_to_line", normal_k=12)
+        assert "ICP converged: iter=5, error=0.00034245" in capsys.readouterr().out
+    finally:
+        uicp.VERBOSE = False
+
+
+def test_icp_batch_equals_single_and_oracle(uicp):
+    from icpmi import batch, synth
+    srcs, tgts = synth.loop_closure_batch(12, seed0=4000)
+    R, t, err, info = batch.icp_batch(srcs, tgts, 1e-10, 150, 0.04, method="point_to_line", normal_k=12)
+    for i in range(12):
+        Ro, to, eo, io = oracle.icp(srcs[i], tgts[i], 1e-10, 150, 0.04, method="point_to_line", normal_k=12)
+        assert rot_err(R[i], t[i], Ro, to) < FRO_TOL, i
+        assert info["iters"][i] == io["iters"] and info["status"][i] == io["status"], i
+    # shared source (slam.py:576-579) and point_to_point with rejection
+    R2, t2, e2, i2 = batch.icp_batch(srcs[0], tgts, 1e-10, 150, 0.04, method="point_to_point", max_corr_dist=1.0)
+    for i in (0, 5, 11):
+        Ro, to, eo, io = oracle.icp(srcs[0], tgts[i], 1e-10, 150, 0.04, method="point_to_point", max_corr_dist=1.0)
+        assert rot_err(R2[i], t2[i], Ro, to) < FRO_TOL and i2["iters"][i] == io["iters"]
+
+
+def test_icp_large_clouds_stream_targets(uicp):
+    """Source > 2048 rows (several NN passes) and target > LDS capacity (streamed tiles)."""
+    from icpmi import synth
+    rng = np.random.default_rng(3)
+    segs = synth.maze_segments()
+    tgt = np.vstack([synth.to_world(synth.scan(p, 70 + i, segs=segs), p) for i, p in enumerate(synth.trajectory(8))])
+    th = np.deg2rad(1.5)
+    Rm = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    src = (tgt[rng.permutation(len(tgt))[:6000]] - np.array([0.05, 0.03])) @ Rm.T
+    for method in ("point_to_point", "point_to_line"):
+        R, t, err = uicp.ICP(src, tgt, 1e-10, 60, 0.02, method=method, normal_k=10, max_corr_dist=1.0)
+        Ro, to, eo, io = oracle.icp(src, tgt, 1e-10, 60, 0.02, method=method, normal_k=10, max_corr_dist=1.0)
+        assert io["n_src"] > 2048 and io["n_tgt"] > 3072
+        assert rot_err(R, t, Ro, to) < FRO_TOL and uicp.last_icp_info["iterations"] == io["iters"]
+
+
+# ── occupancy grid ──────────────────────────────────────────────────────────
+def test_bresenham_cells_bit_exact(umap):
+    z = load_golden("bresenham")
+    segs, cells, off = z["segs"], z["cells"], z["off"]
+    got = umap.bresenham_cells(segs)
+    for k in range(len(segs)):
+        assert np.array_equal(got[k], cells[off[k]:off[k + 1]]), segs[k]
+    s = (3, -7, -40, 11)
+    assert umap.OccupancyGrid2D._bresenham(*s) == [tuple(int(v) for v in c) for c in oracle.bresenham(*s)]
+    assert umap.OccupancyGrid2D._bresenham(4, 4, 4, 4) == []
+
+
+def test_world_to_grid(umap):
+    z = load_golden("grid")
+    b = z["small_bounds"]
+    g = umap.OccupancyGrid2D(b[0], b[1], b[2], b[3], resolution=0.05)
+    ix, iy = g._world_to_grid_batch(z["w2g_in"], z["w2g_in"][::-1])
+    assert np.array_equal(ix, z["w2g_ix"]) and np.array_equal(iy, z["w2g_iy"])
+    assert g._world_to_grid(0.0, 0.0) == (120, 100) and g._in_bounds(239, 199) and not g._in_bounds(240, 0)
+
+
+GRID_KW = dict(resolution=0.05, p_hit=0.85, p_miss=0.42, log_odds_min=-8.0, log_odds_max=8.0)
+
+
+def test_update_scan_small_grid_bit_exact(umap):
+    z = load_golden("grid")
+    b = z["small_bounds"]
+    g = umap.OccupancyGrid2D(b[0], b[1], b[2], b[3], **GRID_KW)
+    assert (g.ny, g.nx) == _grid_shape(b, 0.05) and g.log_odds.dtype == np.float32
+    assert np.array_equal([g.l_hit, g.l_miss], z["small_l"])
+    for i in range(40):
+        g.update_scan(z["small_origins"][i], z["small_hits"][i])
+        if i + 1 in (1, 3, 40):
+            assert np.array_equal(g.log_odds, z[f"small_after{i + 1}"]), i
+    assert g.log_odds.min() == -8.0
+    # replay API: all 40 scans in one call (slam.py:271-277 _rebuild_map)
+    g.reset()
+    assert np.abs(g.log_odds).sum() == float(z["small_reset_sum"])
+    g.update_scans(z["small_origins"], list(z["small_hits"]))
+    assert np.array_equal(g.log_odds, z["small_after40"])
+
+
+def test_update_scan_edges_defaults_display(umap):
+    z = load_golden("grid")
+    b = z["small_bounds"]
+    g = umap.OccupancyGrid2D(b[0], b[1], b[2], b[3], **GRID_KW)
+    g.update_scan(z["edge_origin"], z["edge_hits"])          # origin outside, duplicate + outside hits
+    g.update_scan(z["edge_origin"], np.empty((0, 2)))         # empty: silent no-op
+    assert np.array_equal(g.log_odds, z["edge_after"])
+    g = umap.OccupancyGrid2D(b[0], b[1], b[2], b[3])           # default arguments
+    for i in range(3):
+        g.update_scan(z["small_origins"][i], z["small_hits"][i])
+    assert np.array_equal(g.log_odds, z["default_after3"])
+    assert np.array_equal(g.to_probability(), z["default_prob"])
+    assert np.array_equal(g.to_display(), z["default_display"])
+
+
+def test_update_scan_config4_full_grid(umap):
+    z = load_golden("grid")
+    b = z["cfg4_bounds"]
+    g = umap.OccupancyGrid2D(b[0], b[1], b[2], b[3], **GRID_KW)
+    assert (g.ny, g.nx) == tuple(z["cfg4_shape"])
+    g.update_scan(z["cfg4_origin"], z["cfg4_hits"])
+    lo = g.log_odds.ravel()
+    nz = np.flatnonzero(lo)
+    assert np.array_equal(nz, z["cfg4_nz_idx"]) and np.array_equal(lo[nz], z["cfg4_nz_val"])
+
+
+def test_update_scan_clip_semantics_and_wide_scans(umap):
+    rng = np.random.default_rng(5)
+    # clamp range that excludes 0: the first scan clips EVERY cell, like np.clip on the whole grid
+    g = umap.OccupancyGrid2D(-2.0, 2.0, -2.0, 2.0, resolution=0.1, log_odds_min=0.5, log_odds_max=3.0)
+    ref = np.zeros((g.ny, g.nx), dtype=np.float32)
+    hits = rng.uniform(-3, 3, size=(200, 2))
+    for _ in range(2):
+        g.update_scan([0.1, 0.1], hits)
+        oracle.grid_update_scan(ref, g.min_x, g.min_y, 0.1, [0.1, 0.1], hits, g.l_hit, g.l_miss, 0.5, 3.0)
+    assert np.array_equal(g.log_odds, ref)
+    # uploaded grid with out-of-range values
+    g2 = umap.OccupancyGrid2D(-2.0, 2.0, -2.0, 2.0, resolution=0.1)
+    start = rng.normal(scale=6.0, size=(g2.ny, g2.nx)).astype(np.float32)
+    g2.log_odds = start
+    ref = start.copy()
+    g2.update_scan([0.0, 0.0], hits)
+    oracle.grid_update_scan(ref, g2.min_x, g2.min_y, 0.1, [0.0, 0.0], hits, g2.l_hit, g2.l_miss, -5.0, 5.0)
+    assert np.array_equal(g2.log_odds, ref)
+    # more beams than a 16-bit counter holds -> two-round path; p_miss > 0.5 -> positive l_miss
+    g3 = umap.OccupancyGrid2D(-3.0, 3.0, -3.0, 3.0, resolution=0.05, p_hit=0.6, p_miss=0.55)
+    many = rng.uniform(-2.9, 2.9, size=(70000, 2))
+    ref = np.zeros((g3.ny, g3.nx), dtype=np.float32)
+    g3.update_scan([0.5, -0.5], many)
+    oracle.grid_update_scan(ref, g3.min_x, g3.min_y, 0.05, [0.5, -0.5], many, g3.l_hit, g3.l_miss, -5.0, 5.0)
+    assert np.array_equal(g3.log_odds, ref)
+
+
+def test_raycast_full_size_properties(umap):
+    """Config-4 sized grid, 200 scans: size-independent checks beside the oracle on a sample."""
+    from icpmi import synth
+    p0 = (0.3, -0.2, np.deg2rad(10.0))
+    first = synth.to_world(synth.scan(p0, 2), p0)
+    b = (first[:, 0].min() - 50, first[:, 0].max() + 50, first[:, 1].min() - 50, first[:, 1].max() + 50)
+    g = umap.OccupancyGrid2D(*b, **GRID_KW)
+    poses = [(0.3 + 0.02 * i, -0.2 + 0.01 * i, np.deg2rad(10.0 + 0.5 * i)) for i in range(200)]
+    hits = [synth.to_world(synth.scan(p, 2 + i), p) for i, p in enumerate(poses)]
+    org = np.array([[p[0], p[1]] for p in poses])
+    g.update_scans(org, hits)
+    lo = g.log_odds
+    assert lo.min() >= -8.0 and lo.max() <= 8.0                     # clip invariant
+    assert lo.min() == -8.0 and lo.max() == 8.0                     # both clamps reached after 200 scans
+    ref = np.zeros_like(lo)
+    for o, h in zip(org, hits):
+        oracle.grid_update_scan(ref, g.min_x, g.min_y, 0.05, o, h, g.l_hit, g.l_miss, -8.0, 8.0)
+    assert np.array_equal(lo, ref)
+    # replay after reset reproduces the grid exactly (order-preserving, no float atomics)
+    g.reset()
+    g.update_scans(org, hits)
+    assert np.array_equal(g.log_odds, ref)
