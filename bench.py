@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py — ICP iterations/s (+ occupancy cells ray-cast/s) on N MI355X GPUs.
+
+A *step* is one pass of the hot path over one batch of synthetic 2 048-beam scan
+pairs resident in HBM: per pair exactly what the reference's ``ICP()`` call does
+(voxel filter of both scans, target normals, point-to-line ICP to convergence
+with the config.yaml parameters of BASELINE config 2), ``--pairs-per-gpu`` pairs
+per GPU (the batched loop-closure shape of config 5), followed by the all_gather
+of the result records.  Weak scaling: every rank owns its own pairs.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (REPO, os.path.join(REPO, "iterative-closest-point-avmi_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md; 6 290 GB/s measured copy)
+FP64_VALU_PEAK_TOPS = 39.3       # 78.6 TFLOP/s vector FP64 counts an FMA as 2; the NN loop issues plain ops
+ICP_KW = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs-per-gpu", type=int, default=512)
+    ap.add_argument("--raycast-scans", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-raycast", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from icpmi import _lib, synth
+    from icpmi.batch import IcpBatch
+    from icpmi.dist import gather_results
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ── workload: distinct pairs per rank, inputs resident in HBM before timing ──
+    B = args.pairs_per_gpu
+    srcs, tgts = synth.loop_closure_batch(B, seed0=1000 + 100003 * rank)
+    batch = IcpBatch(srcs + tgts, np.arange(B), np.arange(B, 2 * B), **ICP_KW)
+    n_total = B * world
+
+    def step(ev=None):
+        res = batch.run(events=ev)
+        return gather_results(res[:B], n_total, rank, world) if world > 1 else res
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        out = step(events[k])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    res = out.cpu().numpy()                                   # all pairs of all ranks (gathered) or the local batch
+    iters_per_step = float(res[:, _lib.RES_ITERS].sum())
+    value = iters_per_step * args.steps / elapsed
+
+    # ── roofline of the dominant kernel (fused ICP), rank 0's launch ────────────
+    local = batch.results.cpu().numpy()[:B]
+    cnt = batch.vox.cnt.cpu().numpy()
+    N = cnt[batch.pair_src_host].astype(np.float64)
+    M = cnt[batch.pair_tgt_host].astype(np.float64)
+    it = local[:, _lib.RES_ITERS]
+    alg_bytes = float((it * (28.0 * N + 16.0 * M)).sum())    # 16N+16M read + 12N written per pair-iteration
+    evals = float((it * N * M).sum())
+    k_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    roofline = {"kernel": "icp_fused_kernel<2>", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                "valu": {"distance_evals_per_launch": evals, "fp64_ops_per_eval": 6,
+                         "achieved_Tops": round(evals * 6 / (k_ms * 1e-3) / 1e12, 3), "peak_Tops": FP64_VALU_PEAK_TOPS,
+                         "frac": round(evals * 6 / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS, 4)}}
+
+    line = {"metric": "icp_iterations_per_sec", "value": round(value, 1), "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "config 2 scan pairs (2048-beam room scans, point_to_line ICP, voxel 0.04, "
+                                   "normal_k 12, thr 1e-10) batched as in config 5",
+                       "pairs_per_gpu": B, "pairs_total": n_total,
+                       "mean_points_after_voxel": [round(float(N.mean()), 1), round(float(M.mean()), 1)],
+                       "iterations_per_step": iters_per_step, "parallelism": f"pairs sharded over {world} GPU(s)",
+                       "includes": "voxel_downsample x2 + estimate_normals_2d + ICP loop + result all_gather"},
+            "roofline": roofline}
+
+    if rank == 0 and world == 1:
+        # single-pair latency (config 2 exactly as the reference calls it, one pair)
+        one = IcpBatch([srcs[0], tgts[0]], [0], [1], **ICP_KW)
+        for _ in range(3):
+            one.run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            one.run()
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t1) / 50
+        it1 = float(one.results.cpu().numpy()[0, _lib.RES_ITERS])
+        line["single_pair"] = {"ms_per_icp": round(lat * 1e3, 4), "iterations": it1,
+                               "iterations_per_sec": round(it1 / lat, 1)}
+        if not args.no_raycast:
+            line["raycast"] = bench_raycast(torch, synth, args.raycast_scans, not args.no_cpu_baseline)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(srcs, tgts)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_raycast(torch, synth, n_scans, with_cpu):
+    """BASELINE config 4: 2 242 x 2 402 grid @0.05 m, 2 048-beam scans replayed in order (slam.py:271-277 shape)."""
+    from utilities.mapping import OccupancyGrid2D
+    p0 = (0.3, -0.2, np.deg2rad(10.0))
+    first = synth.to_world(synth.scan(p0, 2), p0)
+    b = (first[:, 0].min() - 50, first[:, 0].max() + 50, first[:, 1].min() - 50, first[:, 1].max() + 50)
+    g = OccupancyGrid2D(*b, resolution=0.05, p_hit=0.85, p_miss=0.42, log_odds_min=-8.0, log_odds_max=8.0)
+    poses = [(0.3 + 0.02 * i, -0.2 + 0.01 * i, np.deg2rad(10.0 + 0.5 * i)) for i in range(n_scans)]
+    hits = [synth.to_world(synth.scan(p, 2 + i), p) for i, p in enumerate(poses)]
+    org = np.array([[p[0], p[1]] for p in poses])
+    # cell updates = in-bounds hit adds + free cells; every ray lies inside this grid (50 m margin)
+    cells = 0
+    for o, h in zip(org, hits):
+        ox, oy = np.floor((o[0] - g.min_x) / 0.05), np.floor((o[1] - g.min_y) / 0.05)
+        hx, hy = np.floor((h[:, 0] - g.min_x) / 0.05), np.floor((h[:, 1] - g.min_y) / 0.05)
+        cells += int(np.maximum(np.abs(hx - ox), np.abs(hy - oy)).sum()) + len(h)
+    d_org = torch.from_numpy(org).cuda()
+    d_hits = torch.from_numpy(np.concatenate(hits)).cuda()
+    off = np.zeros(n_scans + 1, dtype=np.int32)
+    np.cumsum([len(h) for h in hits], out=off[1:])
+    g._apply(d_org, d_hits, off)                                 # warm-up
+    g.reset()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    g._apply(d_org, d_hits, off)
+    e1.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_time(e1)
+    out = {"workload": f"config 4 grid {g.ny}x{g.nx}, {n_scans} scans x 2048 beams replayed in order",
+           "cell_updates": cells, "cells_per_sec": round(cells / wall, 1), "ms_per_scan": round(wall / n_scans * 1e3, 5),
+           "device_ms_per_scan": round(dev_ms / n_scans, 5),
+           "roofline": {"bound": "hbm", "achieved": round((8.0 * cells + 16.0 * 2048 * n_scans) / wall / 1e9, 3),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round((8.0 * cells + 16.0 * 2048 * n_scans) / wall / 1e9 / HBM_PEAK_GBS, 6)}}
+    if with_cpu:
+        import oracle
+        ref = np.zeros((g.ny, g.nx), dtype=np.float32)
+        t0 = time.perf_counter()
+        n = 0
+        for o, h in list(zip(org, hits))[:20]:
+            n += oracle.grid_update_scan(ref, g.min_x, g.min_y, 0.05, o, h, g.l_hit, g.l_miss, -8.0, 8.0)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(n / dt, 1), "unit": "cells/s", "cores": 1, "kind": "port",
+                               "sample": "first 20 scans, C oracle (includes the reference's whole-grid clip per scan)"}
+    return out
+
+
+def cpu_baseline(srcs, tgts):
+    """The C oracle (k-d tree search, same algorithm as the reference's ICP) on this box's host, one core."""
+    import oracle
+    oracle.icp(srcs[0], tgts[0], **ICP_KW)
+    t0 = time.perf_counter()
+    iters = n = 0
+    for s, t in zip(srcs, tgts):
+        iters += oracle.icp(s, t, **ICP_KW)[3]["iters"]
+        n += 1
+        if time.perf_counter() - t0 > 15.0:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(iters / dt, 1), "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of the same scan pairs, {iters} iterations, {dt:.1f} s, oracle/icp_oracle.c (k-d tree NN)",
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -200,8 +200,10 @@ class IcpBatch:
                                   dtype=torch.uint8, device=dev)
         self.results = torch.zeros((max(self.B, 1), _lib.RES_DOUBLES), dtype=torch.float64, device=dev)
 
-    def run(self):
-        """Enqueue voxel filter -> normals -> fused ICP on the current stream; returns the device result tensor."""
+    def run(self, events=None):
+        """Enqueue voxel filter -> normals -> fused ICP on the current stream; returns the device result tensor.
+
+        events: optional (start, end) torch.cuda.Event pair recorded around the fused ICP launch only."""
         L = _lib.lib()
         st = _stream()
         voxel_downsample_set(self.raw, self.voxel_size, out=self.vox, workspace=self.vox_ws)
@@ -210,10 +212,14 @@ class IcpBatch:
                                            _ptr(self.tgt_ids_dev), len(self.tgt_ids), self.raw.total_rows,
                                            self.nrm_max_n, self.normal_k, _ptr(self.normals), _ptr(self.nrm_ws),
                                            self.nrm_ws.numel(), st), "estimate_normals_2d")
+        if events is not None:
+            events[0].record()
         check(L.icpmi_icp_batch(_ptr(self.vox.pts), _ptr(self.vox.off), _ptr(self.vox.cnt), _ptr(self.normals),
                                 _ptr(self.pair_src), _ptr(self.pair_tgt), self.B, self.max_src_n,
                                 C.byref(self.params), _ptr(self.init), _ptr(self.results), _ptr(self.icp_ws),
                                 self.icp_ws.numel(), st), "ICP")
+        if events is not None:
+            events[1].record()
         return self.results
 
     def unpack(self, results=None):

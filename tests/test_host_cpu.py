@@ -1,0 +1,132 @@
+"""CPU-side checks: the C-ABI library builds, loads and exports every symbol the
+header declares; the product path refuses to run without a GPU (no CPU
+fallback); the multi-rank sharding/gather logic works under gloo with
+world_size 2 (the oracle is injected as the local solver — test only)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, REPO
+
+HEADER = os.path.join(REPO, "include", "icpmi.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(icpmi_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    import ctypes
+    import icpmi
+    path = icpmi.build()
+    L = ctypes.CDLL(path)
+    syms = declared_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/icpmi.h but not exported"
+    # and the Python binding knows every one of them
+    from icpmi import _lib
+    assert sorted(_lib.EXPORTS) == syms
+    lib = icpmi.lib()
+    assert lib.icpmi_version().decode().startswith("icpmi")
+    assert lib.icpmi_strerror(-2).decode() == "workspace missing or too small"
+    # host-only size queries (no GPU touched)
+    assert lib.icpmi_grid_workspace_bytes(10, 20) == 10 * 20 * 4 + 256
+    assert lib.icpmi_icp_workspace_bytes(2, 100, 2) == 2 * 100 * (16 + 8 + 4) + 256
+    assert lib.icpmi_voxel_workspace_bytes(2048) == 256
+    assert lib.icpmi_voxel_workspace_bytes(100000) > 100000 * 24
+
+
+def test_struct_layout_matches_header():
+    import ctypes
+    from icpmi._lib import IcpParams
+    assert ctypes.sizeof(IcpParams) == 32
+    assert IcpParams.max_iterations.offset == 16 and IcpParams.dim.offset == 28
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from icpmi import IcpmiError
+    from utilities import icp as uicp
+    from utilities.mapping import OccupancyGrid2D
+    pts = np.random.default_rng(0).normal(size=(100, 2))
+    with pytest.raises(IcpmiError):
+        uicp.ICP(pts, pts, 1e-6, 10, 0.1)
+    with pytest.raises(IcpmiError):
+        uicp.voxel_downsample(pts, 0.1)
+    with pytest.raises(IcpmiError):
+        OccupancyGrid2D(-1, 1, -1, 1)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under the package or bench's GPU legs may import it."""
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(import oracle|from oracle)", src, flags=re.M), f
+                assert "liboracle" not in src, f
+
+
+def test_shard_and_gather_single_process():
+    import torch
+    from icpmi import dist as idist
+    assert list(idist.shard(10, 1, 4)) == [1, 5, 9]
+    assert idist.slots_per_rank(10, 4) == 3
+    loc = torch.arange(5 * 16, dtype=torch.float64).reshape(5, 16)
+    out = idist.gather_results(loc, 5, 0, 1)
+    assert torch.equal(out, loc)
+    res = torch.zeros((4, 16), dtype=torch.float64)
+    res[:, 12] = torch.tensor([0.5, 0.2, 0.01, 0.001])
+    assert idist.first_accepted(res, 0.05) == 2 and idist.first_accepted(res, 1e-6) == -1
+
+
+WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {pkg!r})
+import oracle
+from icpmi import dist as idist, synth, _lib
+
+def solver(src, tgt, Ri, ti):
+    out = np.zeros((len(tgt), _lib.RES_DOUBLES))
+    for i, (s, t) in enumerate(zip(src, tgt)):
+        R, tt, err, info = oracle.icp(s, t, 1e-10, 60, 0.1, method="point_to_line", normal_k=8)
+        out[i, :4] = R.ravel(); out[i, 9:11] = tt; out[i, 12] = err
+        out[i, 14] = info["iters"]; out[i, 15] = info["status"]
+    return torch.from_numpy(out)
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+srcs, tgts = synth.loop_closure_batch(5, seed0=77)
+srcs = [s[::4] for s in srcs]; tgts = [t[::4] for t in tgts]
+res = idist.icp_batch_sharded(srcs, tgts, 1e-10, 60, 0.1, method="point_to_line", normal_k=8, solver=solver)
+full = solver(srcs, tgts, None, None)            # every pair locally, in order
+assert res.shape == (5, _lib.RES_DOUBLES)
+assert torch.equal(res, full), (rank, (res - full).abs().max())
+shared = idist.icp_batch_sharded(srcs[0], tgts, 1e-10, 60, 0.1, solver=solver)
+assert torch.equal(shared, solver([srcs[0]] * 5, tgts, None, None))
+dist.barrier()
+if rank == 0:
+    print("GLOO_OK", world)
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_batch_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(repo=REPO, pkg=PKG))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29713", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "GLOO_OK 2" in r.stdout
