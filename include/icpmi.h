@@ -120,13 +120,35 @@ int icpmi_p2l_solve_2d(const double* src, int32_t n_src, const double* tgt, cons
  * normals: same row layout as pts (only rows of target clouds are read; may be
  * NULL for point_to_point).  init: [n_pairs][dim*dim + dim] (R then t) or NULL.
  * results: [n_pairs][ICPMI_RES_DOUBLES].  max_src_n bounds the valid rows of
- * any source cloud (sizes the workspace). */
+ * any source cloud, max_tgt_n those of any target cloud, total_rows = off[C].
+ *
+ * prepared (optional): buffer filled by icpmi_prepare_targets for the target
+ * clouds of this batch.  With it, 2-D pairs whose clouds have at most 4096 rows
+ * run on the fast kernel (exact sweep search on the axis-sorted target copy,
+ * pair state in LDS/registers; `normals` and `workspace` are then not read).
+ * Without it, or for 3-D / larger clouds, the exhaustive LDS-tiled kernel runs
+ * and needs `workspace` (and `normals` for point_to_line).  Results agree. */
 size_t icpmi_icp_workspace_bytes(int32_t n_pairs, int32_t max_src_n, int32_t dim);
 int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
-                    const double* normals, const int32_t* pair_src, const int32_t* pair_tgt,
-                    int32_t n_pairs, int32_t max_src_n, const icpmi_icp_params* params_host,
-                    const double* init, double* results,
+                    const double* normals, const void* prepared,
+                    const int32_t* pair_src, const int32_t* pair_tgt,
+                    int32_t n_pairs, int32_t max_src_n, int32_t max_tgt_n, int32_t total_rows,
+                    const icpmi_icp_params* params_host, const double* init, double* results,
                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- prepared targets: axis choice + sort (+ normals) for the sweep search ----
+ * For every selected cloud (<= 4096 rows): pick the projection axis (x, y, x+y
+ * or x-y) with the smallest expected search window, sort the cloud along it and
+ * store the sorted points, the sorted->row map and the axis in `prepared`
+ * (icpmi_prepared_bytes(total_rows, n_clouds) bytes).  normal_k >= 0 also
+ * computes estimate_normals_2d (icp.py:51-76) with k = normal_k: stored in
+ * sorted order inside `prepared`, and in row order in out_normals if given.
+ * normal_k < 0 skips normals (point_to_point). */
+size_t icpmi_prepared_bytes(int32_t total_rows, int32_t n_clouds);
+int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
+                          const int32_t* cloud_ids, int32_t n_sel, int32_t n_clouds,
+                          int32_t total_rows, int32_t max_n, int32_t normal_k,
+                          double* out_normals, void* prepared, size_t prepared_bytes, void* stream);
 
 /* ---- OccupancyGrid2D, utilities/mapping.py ---------------------------------
  * world -> cell index, mapping.py:57-60,94-98: floor((w - min) / res), float64

@@ -304,18 +304,30 @@ extern "C" size_t icpmi_icp_workspace_bytes(int32_t n_pairs, int32_t max_src_n, 
     return rows * dim * sizeof(double) + rows * sizeof(double) + rows * sizeof(int32_t) + 256;
 }
 
+namespace icpmi {
+int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const int32_t* ps, const int32_t* pt,
+                int n_pairs, int max_src_n, int max_tgt_n, int total_rows, const icpmi_icp_params* p, const double* init,
+                double* results, const void* prepared, hipStream_t st);   // icp2.hip
+}
+
 extern "C" int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
-                               const double* normals, const int32_t* pair_src, const int32_t* pair_tgt,
-                               int32_t n_pairs, int32_t max_src_n, const icpmi_icp_params* p,
-                               const double* init, double* results, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+                               const double* normals, const void* prepared,
+                               const int32_t* pair_src, const int32_t* pair_tgt,
+                               int32_t n_pairs, int32_t max_src_n, int32_t max_tgt_n, int32_t total_rows,
+                               const icpmi_icp_params* p, const double* init, double* results,
+                               void* workspace, size_t workspace_bytes, void* stream) {
     using namespace icpmi;
     if (!pts || !off_dev || !pair_src || !pair_tgt || !p || !results) return ICPMI_ERR_ARG;
-    if (n_pairs < 0 || max_src_n < 0 || (p->dim != 2 && p->dim != 3)) return ICPMI_ERR_ARG;
+    if (n_pairs < 0 || max_src_n < 0 || max_tgt_n < 0 || (p->dim != 2 && p->dim != 3)) return ICPMI_ERR_ARG;
     if (p->method != ICPMI_POINT_TO_POINT && p->method != ICPMI_POINT_TO_LINE) return ICPMI_ERR_ARG;
     if (p->has_init && !init) return ICPMI_ERR_ARG;
-    if (p->method == ICPMI_POINT_TO_LINE && p->dim == 2 && !normals) return ICPMI_ERR_ARG;
     if (n_pairs == 0) return ICPMI_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // fast path: prepared (axis-sorted) targets, everything on chip
+    if (prepared && p->dim == 2 && max_src_n <= 4096 && max_tgt_n <= 4096)
+        return launch_icp2(pts, off_dev, cnt_dev, pair_src, pair_tgt, n_pairs, max_src_n, max_tgt_n, total_rows, p, init,
+                           results, prepared, st);
+    if (p->method == ICPMI_POINT_TO_LINE && p->dim == 2 && !normals) return ICPMI_ERR_ARG;
     if (!workspace || workspace_bytes < icpmi_icp_workspace_bytes(n_pairs, max_src_n, p->dim)) return ICPMI_ERR_WORKSPACE;
     const size_t rows = (size_t)n_pairs * (size_t)max_src_n;
     IcpArgs a;
@@ -327,7 +339,6 @@ extern "C" int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const 
     a.max_src_n = max_src_n;
     a.error_threshold = p->error_threshold; a.max_corr_dist = p->max_corr_dist;
     a.max_iterations = p->max_iterations; a.method = p->method; a.has_init = p->has_init;
-    hipStream_t st = (hipStream_t)stream;
     if (p->dim == 2) icp_fused_kernel<2><<<n_pairs, ICP_THREADS, 0, st>>>(a);
     else icp_fused_kernel<3><<<n_pairs, ICP_THREADS, 0, st>>>(a);
     ICPMI_LAUNCH_CHECK();

@@ -1,0 +1,91 @@
+// sweep.hpp — exact nearest-neighbour search on a cloud sorted along one axis.
+//
+// The target cloud is sorted by a projection u(p) along one of four axes
+// (x, y, x+y, x-y; the prepare kernel picks the one with the fewest expected
+// candidates).  A query starts at the position of its own projection (binary
+// search) and walks outwards on both sides.  |u(q) - u(c)| bounds the distance
+// from below (by |q-c| on the two coordinate axes, by sqrt(2)|q-c| on the
+// diagonals), so a side stops at the first candidate whose projection gap
+// already exceeds the best squared distance found.  Exact: the winner, its
+// float64 squared distance (direct differences, no FMA) and the lowest-row
+// tie rule are those of the exhaustive scan in nn.hpp — only the candidates that
+// cannot win are skipped.  Typical windows are ~10 candidates instead of the
+// whole cloud.
+#pragma once
+#include "common.hpp"
+
+namespace icpmi {
+
+// projection value along axis `dir`
+__device__ __forceinline__ double proj(int dir, double x, double y) {
+    return dir == 0 ? x : (dir == 1 ? y : (dir == 2 ? x + y : x - y));
+}
+
+// Lower bound on the squared distance implied by a projection gap, with the
+// rounding of the diagonal projections accounted for (conservative: a candidate
+// is only skipped when it provably cannot win).  uq, uc: projections.
+__device__ __forceinline__ bool gap_exceeds(int dir, double uq, double uc, double bound_d2) {
+    const double du = fabs(uq - uc);
+    if (dir < 2) return du * du > bound_d2;            // same subtraction as inside the distance: exact
+    const double e = 4.5e-16 * (fabs(uq) + fabs(uc));  // fl(x +- y) is within 2^-53 relative of the true sum
+    const double l = du - e;
+    return l > 0.0 && l * l > bound_d2 * 2.000000000000002;   // (dx +- dy)^2 <= 2 (dx^2 + dy^2)
+}
+
+// first position in [0, m) whose projection is >= uq (m if none); sxy = sorted (x, y) pairs
+__device__ __forceinline__ int sweep_lower_bound(const double2* sxy, int m, int dir, double uq) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double2 c = sxy[mid];
+        if (proj(dir, c.x, c.y) < uq) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// 1-NN of (qx, qy) in the sorted cloud.  Returns the sorted position; d2 is the
+// squared distance; ties go to the lowest original row (sorig).
+__device__ __forceinline__ int sweep_nn(const double2* sxy, const int32_t* sorig, int m, int dir,
+                                        double qx, double qy, double& d2_out) {
+    const double uq = proj(dir, qx, qy);
+    const int p0 = sweep_lower_bound(sxy, m, dir, uq);
+    int lo = p0 - 1, hi = p0;
+    double best = __builtin_inf();
+    int bpos = 0, brow = 0x7fffffff;
+    while (lo >= 0 || hi < m) {
+        if (hi < m) {
+            const double2 c = sxy[hi];
+            if (gap_exceeds(dir, uq, proj(dir, c.x, c.y), best)) hi = m;
+            else {
+                const double dx = qx - c.x, dy = qy - c.y;
+                double s = 0.0;
+                s += dx * dx;
+                s += dy * dy;
+                if (s <= best) {
+                    const int row = sorig[hi];
+                    if (s < best || row < brow) { best = s; bpos = hi; brow = row; }
+                }
+                ++hi;
+            }
+        }
+        if (lo >= 0) {
+            const double2 c = sxy[lo];
+            if (gap_exceeds(dir, uq, proj(dir, c.x, c.y), best)) lo = -1;
+            else {
+                const double dx = qx - c.x, dy = qy - c.y;
+                double s = 0.0;
+                s += dx * dx;
+                s += dy * dy;
+                if (s <= best) {
+                    const int row = sorig[lo];
+                    if (s < best || row < brow) { best = s; bpos = lo; brow = row; }
+                }
+                --lo;
+            }
+        }
+    }
+    d2_out = best;
+    return bpos;
+}
+
+}  // namespace icpmi

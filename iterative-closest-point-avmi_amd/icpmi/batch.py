@@ -18,6 +18,9 @@ from . import _lib
 from ._lib import IcpmiError, IcpParams, check
 
 
+PREP_MAX_POINTS = 4096      # clouds up to this many rows take the sorted-sweep kernels (prep.hip, icp2.hip)
+
+
 def require_gpu():
     if not torch.cuda.is_available():
         raise IcpmiError("libicpmi needs an AMD GPU (gfx950); torch.cuda.is_available() is False "
@@ -119,6 +122,15 @@ def normals_set(cs, k, cloud_ids=None, out=None, workspace=None):
         n_sel = len(ids)
         max_n = int(np.diff(cs.off_host)[ids].max()) if n_sel else 0
         ids_t = torch.from_numpy(ids).to(cs.pts.device)
+    if max_n <= PREP_MAX_POINTS:
+        # sweep search on the axis-sorted copy (prep.hip); the sorted copy is a by-product
+        need = L.icpmi_prepared_bytes(cs.total_rows, cs.n_clouds)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, dtype=torch.uint8, device=cs.pts.device)
+        check(L.icpmi_prepare_targets(_ptr(cs.pts), _ptr(cs.off), _ptr(cs.cnt), _ptr(ids_t), n_sel, cs.n_clouds,
+                                      cs.total_rows, max_n, int(k), _ptr(out), _ptr(workspace), workspace.numel(),
+                                      _stream()), "estimate_normals_2d")
+        return out
     need = L.icpmi_normals_workspace_bytes(cs.total_rows, max_n)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.uint8, device=cs.pts.device)
@@ -153,7 +165,8 @@ class IcpBatch:
     """
 
     def __init__(self, clouds, pair_src, pair_tgt, error_threshold, max_iterations, voxel_size,
-                 R_init=None, t_init=None, method="point_to_point", normal_k=10, max_corr_dist=None):
+                 R_init=None, t_init=None, method="point_to_point", normal_k=10, max_corr_dist=None,
+                 force_exhaustive=False):
         require_gpu()
         L = _lib.lib()
         self.raw = clouds if isinstance(clouds, CloudSet) else CloudSet.from_numpy(clouds)
@@ -190,14 +203,23 @@ class IcpBatch:
                             cnt=torch.zeros(max(self.raw.n_clouds, 1), dtype=torch.int32, device=dev), off=self.raw.off)
         self.vox_ws = torch.empty(L.icpmi_voxel_workspace_bytes(self.raw.max_n), dtype=torch.uint8, device=dev)
         self.normals = None
-        if use_p2l:
-            self.normals = torch.zeros((max(self.raw.total_rows, 1), 2), dtype=torch.float64, device=dev)
-            self.tgt_ids_dev = torch.from_numpy(self.tgt_ids.astype(np.int32)).to(dev)
-            self.nrm_max_n = int(sizes[self.tgt_ids].max()) if len(self.tgt_ids) else 0
-            self.nrm_ws = torch.empty(L.icpmi_normals_workspace_bytes(self.raw.total_rows, self.nrm_max_n),
+        self.tgt_ids_dev = torch.from_numpy(self.tgt_ids.astype(np.int32)).to(dev)
+        self.max_tgt_n = int(sizes[self.tgt_ids].max()) if len(self.tgt_ids) else 0
+        # fast path: 2-D, every cloud small enough for the on-chip kernels
+        self.fast = (self.dim == 2 and self.max_src_n <= PREP_MAX_POINTS and self.max_tgt_n <= PREP_MAX_POINTS
+                     and not force_exhaustive)
+        self.prepared = None
+        self.icp_ws = None
+        if self.fast:
+            self.prepared = torch.empty(L.icpmi_prepared_bytes(self.raw.total_rows, self.raw.n_clouds),
+                                        dtype=torch.uint8, device=dev)
+        else:
+            if use_p2l:
+                self.normals = torch.zeros((max(self.raw.total_rows, 1), 2), dtype=torch.float64, device=dev)
+                self.nrm_ws = torch.empty(L.icpmi_normals_workspace_bytes(self.raw.total_rows, self.max_tgt_n),
+                                          dtype=torch.uint8, device=dev)
+            self.icp_ws = torch.empty(L.icpmi_icp_workspace_bytes(self.B, self.max_src_n, self.dim),
                                       dtype=torch.uint8, device=dev)
-        self.icp_ws = torch.empty(L.icpmi_icp_workspace_bytes(self.B, self.max_src_n, self.dim),
-                                  dtype=torch.uint8, device=dev)
         self.results = torch.zeros((max(self.B, 1), _lib.RES_DOUBLES), dtype=torch.float64, device=dev)
 
     def run(self, events=None):
@@ -207,17 +229,23 @@ class IcpBatch:
         L = _lib.lib()
         st = _stream()
         voxel_downsample_set(self.raw, self.voxel_size, out=self.vox, workspace=self.vox_ws)
-        if self.use_p2l:
+        if self.fast:
+            check(L.icpmi_prepare_targets(_ptr(self.vox.pts), _ptr(self.vox.off), _ptr(self.vox.cnt),
+                                          _ptr(self.tgt_ids_dev), len(self.tgt_ids), self.raw.n_clouds,
+                                          self.raw.total_rows, self.max_tgt_n, self.normal_k if self.use_p2l else -1,
+                                          None, _ptr(self.prepared), self.prepared.numel(), st), "prepare_targets")
+        elif self.use_p2l:
             check(L.icpmi_normals_2d_batch(_ptr(self.vox.pts), _ptr(self.vox.off), _ptr(self.vox.cnt),
                                            _ptr(self.tgt_ids_dev), len(self.tgt_ids), self.raw.total_rows,
-                                           self.nrm_max_n, self.normal_k, _ptr(self.normals), _ptr(self.nrm_ws),
+                                           self.max_tgt_n, self.normal_k, _ptr(self.normals), _ptr(self.nrm_ws),
                                            self.nrm_ws.numel(), st), "estimate_normals_2d")
         if events is not None:
             events[0].record()
         check(L.icpmi_icp_batch(_ptr(self.vox.pts), _ptr(self.vox.off), _ptr(self.vox.cnt), _ptr(self.normals),
-                                _ptr(self.pair_src), _ptr(self.pair_tgt), self.B, self.max_src_n,
+                                _ptr(self.prepared), _ptr(self.pair_src), _ptr(self.pair_tgt), self.B,
+                                self.max_src_n, self.max_tgt_n, self.raw.total_rows,
                                 C.byref(self.params), _ptr(self.init), _ptr(self.results), _ptr(self.icp_ws),
-                                self.icp_ws.numel(), st), "ICP")
+                                self.icp_ws.numel() if self.icp_ws is not None else 0, st), "ICP")
         if events is not None:
             events[1].record()
         return self.results
@@ -239,7 +267,7 @@ def unpack_results(res, dim):
 
 
 def icp_batch(sources, targets, error_threshold, max_iterations, voxel_size, R_init=None, t_init=None,
-              method="point_to_point", normal_k=10, max_corr_dist=None):
+              method="point_to_point", normal_k=10, max_corr_dist=None, force_exhaustive=False):
     """Register sources[i] onto targets[i] for every i; same per-pair semantics as the reference ``ICP``.
 
     ``sources`` may be one array shared by every pair (the loop-closure shape,
@@ -259,6 +287,6 @@ def icp_batch(sources, targets, error_threshold, max_iterations, voxel_size, R_i
         ps = np.arange(B, dtype=np.int32)
         pt = np.arange(B, 2 * B, dtype=np.int32)
     batch = IcpBatch(clouds, ps, pt, error_threshold, max_iterations, voxel_size, R_init, t_init,
-                     method, normal_k, max_corr_dist)
+                     method, normal_k, max_corr_dist, force_exhaustive)
     batch.run()
     return batch.unpack()

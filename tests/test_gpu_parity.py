@@ -317,3 +317,55 @@ def test_raycast_full_size_properties(umap):
     g.reset()
     g.update_scans(org, hits)
     assert np.array_equal(g.log_odds, ref)
+
+
+# ── fast (sorted-sweep) path vs exhaustive path ─────────────────────────────
+def test_fast_path_equals_exhaustive_path(uicp):
+    """icp2.hip + prep.hip must pick the same correspondences as the exhaustive kernels of icp.hip / normals.hip."""
+    from icpmi import batch, synth
+    srcs, tgts = synth.loop_closure_batch(16, seed0=9000)
+    for kw in (dict(method="point_to_line", normal_k=12), dict(method="point_to_point", max_corr_dist=0.8),
+               dict(method="point_to_line", normal_k=5, max_corr_dist=0.5)):
+        fast = batch.IcpBatch(srcs + tgts, np.arange(16), np.arange(16, 32), 1e-10, 150, 0.04, **kw)
+        slow = batch.IcpBatch(srcs + tgts, np.arange(16), np.arange(16, 32), 1e-10, 150, 0.04, force_exhaustive=True, **kw)
+        assert fast.fast and not slow.fast
+        fast.run(); slow.run()
+        Rf, tf, ef, inf_ = fast.unpack()
+        Rs, ts, es, ins = slow.unpack()
+        assert np.array_equal(inf_["iters"], ins["iters"]) and np.array_equal(inf_["status"], ins["status"])
+        assert np.abs(Rf - Rs).max() < 1e-12 and np.abs(tf - ts).max() < 1e-12 and np.abs(ef - es).max() < 1e-14
+    # initial guess + rotated world (diagonal walls: exercises the x+y / x-y sort axes)
+    th = np.deg2rad(41.0)
+    Rw = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    s2 = [s @ Rw.T + 100.0 for s in srcs[:6]]
+    t2 = [t @ Rw.T + 100.0 for t in tgts[:6]]
+    Ri = np.array([[np.cos(0.01), -np.sin(0.01)], [np.sin(0.01), np.cos(0.01)]])
+    R, t, err, info = batch.icp_batch(s2, t2, 1e-10, 150, 0.04, R_init=Ri, t_init=np.array([0.02, -0.01]),
+                                      method="point_to_line", normal_k=12)
+    for i in range(6):
+        Ro, to, eo, io = oracle.icp(s2[i], t2[i], 1e-10, 150, 0.04, R_init=Ri, t_init=np.array([0.02, -0.01]),
+                                    method="point_to_line", normal_k=12)
+        assert rot_err(R[i], t[i], Ro, to) < FRO_TOL and info["iters"][i] == io["iters"], i
+
+
+def test_sweep_nn_adversarial_layouts(uicp):
+    """Clouds that stress the sweep search: one vertical wall (all x equal), exact duplicates, far-away queries."""
+    from icpmi import batch
+    rng = np.random.default_rng(8)
+    wall = np.stack([np.full(900, 2.5), np.linspace(-5, 5, 900)], 1)
+    dup = np.repeat(rng.uniform(-1, 1, size=(100, 2)), 5, axis=0)
+    cases = [(wall + rng.normal(scale=1e-3, size=wall.shape), wall),
+             (dup + 0.01, dup),
+             (rng.uniform(50, 60, size=(400, 2)), rng.uniform(-1, 1, size=(700, 2)))]
+    # These geometries are degenerate for ICP itself (a single wall lets the solution slide), so the
+    # check is between the two search strategies, which share every other instruction: equal
+    # correspondences give equal iterates.
+    for src, tgt in cases:
+        for method in ("point_to_point", "point_to_line"):
+            kw = dict(method=method, normal_k=6)
+            f = batch.IcpBatch([src, tgt], [0], [1], 1e-12, 30, 1e-4, **kw)
+            e = batch.IcpBatch([src, tgt], [0], [1], 1e-12, 30, 1e-4, force_exhaustive=True, **kw)
+            f.run(); e.run()
+            rf, re_ = f.results.cpu().numpy()[0], e.results.cpu().numpy()[0]
+            assert rf[14] == re_[14] and rf[15] == re_[15], (rf[14:], re_[14:])
+            assert np.allclose(rf[:13], re_[:13], rtol=0, atol=1e-9 * max(1.0, np.abs(re_[:13]).max()))
