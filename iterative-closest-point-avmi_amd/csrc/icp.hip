@@ -80,7 +80,13 @@ __device__ __forceinline__ void icp_nn_pass(const double* __restrict__ P, int N,
 template <int DIM>
 __global__ __launch_bounds__(ICP_THREADS) void icp_fused_kernel(IcpArgs a) {
     __shared__ __attribute__((aligned(16))) double tile[ICP_TILE_DOUBLES];
-    __shared__ double red[10 * ICP_MAXW];
+    __shared__ double redA[block_sum_doubles<10>()];
+    __shared__ double redB[block_sum_doubles<DIM * DIM>()];
+    __shared__ double redC[block_sum_doubles<1>()];
+    block_sum_init(redA, block_sum_doubles<10>());
+    block_sum_init(redB, block_sum_doubles<DIM * DIM>());
+    block_sum_init(redC, block_sum_doubles<1>());
+    __syncthreads();
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_fused_kernel(IcpArgs a) {
                         acc[6] += c * bi; acc[7] += nx * bi; acc[8] += ny * bi;
                         acc[9] += 1.0;
                     }
-                    block_sum<10, ICP_MAXW>(acc, red);
+                    block_sum<10, ICP_MAXW>(acc, redA);
                     if (has_corr && acc[9] < (double)need) { status = ICPMI_ST_FEW_INLIERS; break; }
                     double A[3][3] = {{acc[0], acc[1], acc[2]}, {acc[1], acc[3], acc[4]}, {acc[2], acc[4], acc[5]}};
                     double rhs[3] = {acc[6], acc[7], acc[8]}, x[3];
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_fused_kernel(IcpArgs a) {
                     }
                     m[2 * DIM] += 1.0;
                 }
-                block_sum<2 * DIM + 1, ICP_MAXW>(m, red);
+                block_sum<2 * DIM + 1, ICP_MAXW>(m, redA);
                 if (has_corr && m[2 * DIM] < (double)need) { status = ICPMI_ST_FEW_INLIERS; break; }
                 double mp[DIM], mq[DIM];
 #pragma unroll
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_fused_kernel(IcpArgs a) {
 #pragma unroll
                         for (int k = 0; k < DIM; ++k) W[i * DIM + k] += pc[i] * qc[k];
                 }
-                block_sum<DIM * DIM, ICP_MAXW>(W, red);
+                block_sum<DIM * DIM, ICP_MAXW>(W, redB);
                 if constexpr (DIM == 2) kabsch2(W, r); else kabsch3(W, r);
 #pragma unroll
                 for (int i = 0; i < DIM; ++i) {                                 // icp.py:207
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_fused_kernel(IcpArgs a) {
                 }
                 e[0] += se;
             }
-            block_sum<1, ICP_MAXW>(e, red);
+            block_sum<1, ICP_MAXW>(e, redC);
             err = e[0] / (double)N;
             iters = it + 1;
             delta = fabs(prev - err);

@@ -9,8 +9,21 @@
 // thread).  One workgroup per pair, no traffic between workgroups, no host
 // round trip.  Pairs that do not fit (more than 4 rows per thread, target
 // larger than the LDS copy, 3-D) run on the exhaustive kernel of icp.hip.
+#include <cstdlib>
+
 #include "linalg.hpp"
 #include "sweep.hpp"
+
+// -DICPMI_DIAG: a diagnostic build that accumulates s_memtime cycles per phase of
+// the iteration in thread 0 and stores them in the unused R slots 4..8 of the
+// result record (2-D uses 0..3).  Never part of the shipped library.
+#ifdef ICPMI_DIAG
+#define DIAG_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define DIAG_ADD(acc, a, b) acc += (double)((b) - (a))
+#else
+#define DIAG_T(var)
+#define DIAG_ADD(acc, a, b)
+#endif
 
 namespace icpmi {
 
@@ -37,10 +50,15 @@ struct Icp2Args {
 };
 
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void icp2_fused_kernel(Icp2Args a) {
+__global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   // 4 waves/SIMD: 2 x 512 or 1 x 1024 per CU
     constexpr int MAXW = THREADS / ICPMI_WAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    __shared__ double red[10 * MAXW];
+    __shared__ double redA[block_sum_doubles<10>()];   // normal equations / centroids
+    __shared__ double redB[block_sum_doubles<4>()];    // cross-covariance
+    __shared__ double redC[block_sum_doubles<1>()];    // squared error
+    block_sum_init(redA, block_sum_doubles<10>());
+    block_sum_init(redB, block_sum_doubles<4>());
+    block_sum_init(redC, block_sum_doubles<1>());
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -100,12 +118,25 @@ __global__ __launch_bounds__(THREADS) void icp2_fused_kernel(Icp2Args a) {
         const double max_corr_sq = a.max_corr_dist * a.max_corr_dist;   // icp.py:169
         const int need = max(3, N / 10);                                 // icp.py:186
         __syncthreads();
+        // largest |projection| of the target (the copy is sorted along it): rounding slack of the diagonal axes
+        const double2 c_lo = sxy[0], c_hi = sxy[M - 1];
+        const double uabs = fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y)));
+#pragma unroll
+        for (int s = 0; s < ICP2_SMAX; ++s) pos[s] = -1;                 // no previous match yet
 
+#ifdef ICPMI_DIAG
+        double dg_nn = 0, dg_acc = 0, dg_apply = 0, dg_gather = 0, dg_red = 0, dg_solve = 0;
+#endif
         for (int it = 0; it < a.max_iterations; ++it) {
+            DIAG_T(c0);
             // ── correspondences: exact sweep search in LDS, icp.py:179 ───────
 #pragma unroll
             for (int s = 0; s < ICP2_SMAX; ++s)
-                if (s < S && s * THREADS + tid < N) pos[s] = sweep_nn(sxy, sorig, M, dir, px[s], py[s], d2[s]);
+                if (s < S && s * THREADS + tid < N) pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], d2[s]);
+#ifdef ICPMI_DIAG
+            __syncthreads();          // diag only: charge the slowest wave's search to the search phase
+#endif
+            DIAG_T(c1);
             double r[4], t[2];
             if (use_p2l) {
                 // ── point-to-line normal equations, icp.py:88-104 ────────────
@@ -113,8 +144,10 @@ __global__ __launch_bounds__(THREADS) void icp2_fused_kernel(Icp2Args a) {
 #pragma unroll
                 for (int s = 0; s < ICP2_SMAX; ++s) {
                     if (!(s < S && s * THREADS + tid < N)) continue;
-                    const double dist = sqrt(d2[s]);
-                    if (has_corr && !(dist * dist < max_corr_sq)) continue;      // icp.py:184-185
+                    if (has_corr) {                                               // icp.py:184-185
+                        const double dist = sqrt(d2[s]);
+                        if (!(dist * dist < max_corr_sq)) continue;
+                    }
                     const double2 q = sxy[pos[s]], nm = snrm[pos[s]];
                     const double dx = px[s] - q.x, dy = py[s] - q.y;
                     const double c = nm.y * px[s] - nm.x * py[s];
@@ -124,47 +157,60 @@ __global__ __launch_bounds__(THREADS) void icp2_fused_kernel(Icp2Args a) {
                     acc[6] += c * bi;      acc[7] += nm.x * bi;   acc[8] += nm.y * bi;
                     acc[9] += 1.0;
                 }
-                block_sum<10, MAXW>(acc, red);
+                DIAG_T(d0);
+                block_sum<10, MAXW>(acc, redA);
+                DIAG_T(d1);
                 if (has_corr && acc[9] < (double)need) { status = ICPMI_ST_FEW_INLIERS; break; }
                 double A[3][3] = {{acc[0], acc[1], acc[2]}, {acc[1], acc[3], acc[4]}, {acc[2], acc[4], acc[5]}};
                 double rhs[3] = {acc[6], acc[7], acc[8]}, x[3];
                 if (solve3(A, rhs, x)) {
-                    const double ct = cos(x[0]), st = sin(x[0]);                   // icp.py:110-114
+                    double st, ct;
+                    sincos(x[0], &st, &ct);                                        // icp.py:110-114
                     r[0] = ct; r[1] = -st; r[2] = st; r[3] = ct; t[0] = x[1]; t[1] = x[2];
                 } else {
                     r[0] = 1.0; r[1] = 0.0; r[2] = 0.0; r[3] = 1.0; t[0] = 0.0; t[1] = 0.0;
                 }
+#ifdef ICPMI_DIAG
+                DIAG_T(d2);
+                DIAG_ADD(dg_gather, c1, d0); DIAG_ADD(dg_red, d0, d1); DIAG_ADD(dg_solve, d1, d2);
+                if (tid == 0) { res[7] = dg_gather; res[8] = dg_red; res[10 + 1] = dg_solve; }
+#endif
             } else {
                 // ── point-to-point: centroids, centred cross-covariance, icp.py:197-207 ─
                 double m[5] = {0, 0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < ICP2_SMAX; ++s) {
                     if (!(s < S && s * THREADS + tid < N)) continue;
-                    const double dist = sqrt(d2[s]);
-                    if (has_corr && !(dist * dist < max_corr_sq)) continue;
+                    if (has_corr) {
+                        const double dist = sqrt(d2[s]);
+                        if (!(dist * dist < max_corr_sq)) continue;
+                    }
                     const double2 q = sxy[pos[s]];
                     m[0] += px[s]; m[1] += py[s]; m[2] += q.x; m[3] += q.y; m[4] += 1.0;
                 }
-                block_sum<5, MAXW>(m, red);
+                block_sum<5, MAXW>(m, redA);
                 if (has_corr && m[4] < (double)need) { status = ICPMI_ST_FEW_INLIERS; break; }
                 const double mpx = m[0] / m[4], mpy = m[1] / m[4], mqx = m[2] / m[4], mqy = m[3] / m[4];
                 double W[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < ICP2_SMAX; ++s) {
                     if (!(s < S && s * THREADS + tid < N)) continue;
-                    const double dist = sqrt(d2[s]);
-                    if (has_corr && !(dist * dist < max_corr_sq)) continue;
+                    if (has_corr) {
+                        const double dist = sqrt(d2[s]);
+                        if (!(dist * dist < max_corr_sq)) continue;
+                    }
                     const double2 q = sxy[pos[s]];
                     const double pcx = px[s] - mpx, pcy = py[s] - mpy, qcx = q.x - mqx, qcy = q.y - mqy;
                     W[0] += pcx * qcx; W[1] += pcx * qcy; W[2] += pcy * qcx; W[3] += pcy * qcy;
                 }
-                block_sum<4, MAXW>(W, red);
+                block_sum<4, MAXW>(W, redB);
                 kabsch2(W, r);
                 double s0 = 0.0, s1 = 0.0;
                 s0 += r[0] * mpx; s0 += r[1] * mpy;
                 s1 += r[2] * mpx; s1 += r[3] * mpy;
                 t[0] = mqx - s0; t[1] = mqy - s1;                                  // icp.py:207
             }
+            DIAG_T(c2);
             // ── accumulate totals, icp.py:210-211 ────────────────────────────
             {
                 double nr[4], nt[2];
@@ -196,7 +242,12 @@ __global__ __launch_bounds__(THREADS) void icp2_fused_kernel(Icp2Args a) {
                 se += ey * ey;
                 e[0] += se;
             }
-            block_sum<1, MAXW>(e, red);
+            block_sum<1, MAXW>(e, redC);
+            DIAG_T(c3);
+#ifdef ICPMI_DIAG
+            DIAG_ADD(dg_nn, c0, c1); DIAG_ADD(dg_acc, c1, c2); DIAG_ADD(dg_apply, c2, c3);
+            if (tid == 0) { res[4] = dg_nn; res[5] = dg_acc; res[6] = dg_apply; }
+#endif
             err = e[0] / (double)N;
             iters = it + 1;
             delta = fabs(prev - err);
@@ -205,8 +256,10 @@ __global__ __launch_bounds__(THREADS) void icp2_fused_kernel(Icp2Args a) {
         }
     }
     if (tid == 0) {
+#ifndef ICPMI_DIAG
 #pragma unroll
         for (int i = 0; i < ICPMI_RES_DOUBLES; ++i) res[i] = 0.0;
+#endif
         res[0] = rt[0]; res[1] = rt[1]; res[2] = rt[2]; res[3] = rt[3];
         res[ICPMI_RES_T] = tt[0]; res[ICPMI_RES_T + 1] = tt[1];
         res[ICPMI_RES_ERR] = err;
@@ -233,7 +286,11 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     a.error_threshold = p->error_threshold; a.max_corr_dist = p->max_corr_dist;
     a.max_iterations = p->max_iterations; a.method = p->method; a.has_init = p->has_init;
     const size_t lds = (size_t)cap * 36;
-    if (max_src_n <= 512 * ICP2_SMAX) {
+    // rows per thread: 1024-thread workgroups once a source has more than 1024 rows (2 rows per thread
+    // instead of 3-4 shortens the search phase, which is the critical path of a pair)
+    const char* env = getenv("ICPMI_ICP2_THREADS");
+    const int want = env ? atoi(env) : (max_src_n > 1024 ? 1024 : 512);
+    if (want != 1024 && max_src_n <= 512 * ICP2_SMAX) {
         if (hipFuncSetAttribute((const void*)icp2_fused_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP;
         icp2_fused_kernel<512><<<n_pairs, 512, lds, st>>>(a);
     } else {

@@ -11,7 +11,9 @@ constexpr int P2L_THREADS = 512;
 __global__ __launch_bounds__(P2L_THREADS) void p2l_solve_kernel(
     const double* __restrict__ src, int K, const double* __restrict__ tgt, const double* __restrict__ nrm,
     const int32_t* __restrict__ idx, double* __restrict__ out) {
-    __shared__ double red[9 * (P2L_THREADS / ICPMI_WAVE)];
+    __shared__ double red[block_sum_doubles<9>()];
+    block_sum_init(red, block_sum_doubles<9>());
+    __syncthreads();
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = threadIdx.x; i < K; i += P2L_THREADS) {
         const int j = idx[i];

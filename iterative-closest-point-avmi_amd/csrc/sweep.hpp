@@ -43,42 +43,78 @@ __device__ __forceinline__ int sweep_lower_bound(const double2* sxy, int m, int 
     return lo;
 }
 
+// Half-width of the projection window that can still hold a winner: a candidate
+// with |u(q) - u(c)| > prune_width(...) has squared distance > best.  One sqrt
+// per improvement of `best` buys a two-instruction test per candidate.  The
+// factors cover the rounding of the sqrt, of du*du and (diagonals) of x +- y;
+// uabs = max |u| over the target.  Conservative: never skips a possible winner.
+__device__ __forceinline__ double prune_width(int dir, double best, double uq, double uabs) {
+    if (dir < 2) return sqrt(best) * 1.0000000000000004;
+    return sqrt(best * 2.000000000000002) * 1.0000000000000004 + 4.5e-16 * (fabs(uq) + uabs);
+}
+
 // 1-NN of (qx, qy) in the sorted cloud.  Returns the sorted position; d2 is the
-// squared distance; ties go to the lowest original row (sorig).
-__device__ __forceinline__ int sweep_nn(const double2* sxy, const int32_t* sorig, int m, int dir,
-                                        double qx, double qy, double& d2_out) {
+// squared distance; ties go to the lowest original row (sorig).  `start` >= 0 is
+// a position to start from (the previous iteration's match: it seeds the bound
+// and replaces the binary search); any value gives the same answer.
+__device__ __forceinline__ int sweep_nn(const double2* sxy, const int32_t* sorig, int m, int dir, double uabs,
+                                        double qx, double qy, int start, double& d2_out) {
     const double uq = proj(dir, qx, qy);
-    const int p0 = sweep_lower_bound(sxy, m, dir, uq);
-    int lo = p0 - 1, hi = p0;
-    double best = __builtin_inf();
+    double best = __builtin_inf(), thr = __builtin_inf();
     int bpos = 0, brow = 0x7fffffff;
+    int lo, hi;
+    if (start >= 0 && start < m) {
+        const double2 c = sxy[start];
+        const double dx = qx - c.x, dy = qy - c.y;
+        double s = 0.0;
+        s += dx * dx;
+        s += dy * dy;
+        best = s; bpos = start; brow = sorig[start];
+        thr = prune_width(dir, best, uq, uabs);
+        lo = start - 1; hi = start + 1;
+    } else {
+        hi = sweep_lower_bound(sxy, m, dir, uq);
+        lo = hi - 1;
+    }
     while (lo >= 0 || hi < m) {
         if (hi < m) {
             const double2 c = sxy[hi];
-            if (gap_exceeds(dir, uq, proj(dir, c.x, c.y), best)) hi = m;
+            const double du = proj(dir, c.x, c.y) - uq;
+            if (du > thr) hi = m;                               // everything further right is farther still
             else {
-                const double dx = qx - c.x, dy = qy - c.y;
-                double s = 0.0;
-                s += dx * dx;
-                s += dy * dy;
-                if (s <= best) {
-                    const int row = sorig[hi];
-                    if (s < best || row < brow) { best = s; bpos = hi; brow = row; }
+                if (du >= -thr) {
+                    const double dx = qx - c.x, dy = qy - c.y;
+                    double s = 0.0;
+                    s += dx * dx;
+                    s += dy * dy;
+                    if (s <= best) {
+                        const int row = sorig[hi];
+                        if (s < best || row < brow) {
+                            if (s < best) thr = prune_width(dir, s, uq, uabs);
+                            best = s; bpos = hi; brow = row;
+                        }
+                    }
                 }
                 ++hi;
             }
         }
         if (lo >= 0) {
             const double2 c = sxy[lo];
-            if (gap_exceeds(dir, uq, proj(dir, c.x, c.y), best)) lo = -1;
+            const double du = uq - proj(dir, c.x, c.y);
+            if (du > thr) lo = -1;
             else {
-                const double dx = qx - c.x, dy = qy - c.y;
-                double s = 0.0;
-                s += dx * dx;
-                s += dy * dy;
-                if (s <= best) {
-                    const int row = sorig[lo];
-                    if (s < best || row < brow) { best = s; bpos = lo; brow = row; }
+                if (du >= -thr) {
+                    const double dx = qx - c.x, dy = qy - c.y;
+                    double s = 0.0;
+                    s += dx * dx;
+                    s += dy * dy;
+                    if (s <= best) {
+                        const int row = sorig[lo];
+                        if (s < best || row < brow) {
+                            if (s < best) thr = prune_width(dir, s, uq, uabs);
+                            best = s; bpos = lo; brow = row;
+                        }
+                    }
                 }
                 --lo;
             }
