@@ -150,6 +150,17 @@ int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, const int32
                           int32_t total_rows, int32_t max_n, int32_t normal_k,
                           double* out_normals, void* prepared, size_t prepared_bytes, void* stream);
 
+/* Nearest neighbour on prepared targets (same contract as icpmi_nn_batch, same
+ * answers bit for bit, icp.py:179): binary search + outward sweep on the sorted
+ * copy instead of the exhaustive scan.  Target clouds of the pairs must have
+ * been prepared (<= 4096 rows).  out_second_sq (optional) receives the squared
+ * distance of the second nearest target point. */
+int icpmi_nn_prepared_batch(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
+                            const void* prepared, const int32_t* pair_src, const int32_t* pair_tgt,
+                            int32_t n_pairs, int32_t max_src_n, int32_t max_tgt_n, int32_t total_rows,
+                            int32_t* out_idx, double* out_dist, double* out_second_sq,
+                            int32_t out_stride, void* stream);
+
 /* ---- OccupancyGrid2D, utilities/mapping.py ---------------------------------
  * world -> cell index, mapping.py:57-60,94-98: floor((w - min) / res), float64
  * IEEE division, result as int64. */

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(ICP_THREADS) void icp_fused_kernel(IcpArgs a) {
                     double A[3][3] = {{acc[0], acc[1], acc[2]}, {acc[1], acc[3], acc[4]}, {acc[2], acc[4], acc[5]}};
                     double rhs[3] = {acc[6], acc[7], acc[8]}, x[3];
                     if (solve3(A, rhs, x)) {
-                        const double ct = cos(x[0]), st = sin(x[0]);                // icp.py:110-114
+                        double st, ct;
+                        sincos_step(x[0], st, ct);                                  // icp.py:110-114
                         r[0] = ct; r[1] = -st; r[2] = st; r[3] = ct; t[0] = x[1]; t[1] = x[2];
                     } else {
                         r[0] = 1.0; r[1] = 0.0; r[2] = 0.0; r[3] = 1.0; t[0] = 0.0; t[1] = 0.0;

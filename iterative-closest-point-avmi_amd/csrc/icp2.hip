@@ -5,29 +5,40 @@
 // of sweep.hpp over the target copy that prep.hip sorted along its best axis,
 // and everything a pair needs lives on chip: the sorted target points, their
 // normals and the sorted->row map in LDS (36 B per point), the moving source
-// points, their matches and squared distances in registers (up to 4 rows per
-// thread).  One workgroup per pair, no traffic between workgroups, no host
-// round trip.  Pairs that do not fit (more than 4 rows per thread, target
-// larger than the LDS copy, 3-D) run on the exhaustive kernel of icp.hip.
+// points and their matches in registers (up to 4 rows per thread).  One
+// workgroup per pair, no traffic between workgroups, no host round trip.
+//
+// What bounds a pair is the instruction stream of its own workgroup (the tail of
+// a batch is a few pairs that run to max_iterations, each alone on a CU), so
+// work that is uniform across the workgroup is done by ONE wave: wave 0 combines
+// the wave partials, tests convergence, solves the 3x3 system and publishes the
+// step through LDS while the other waves wait at the barrier.  The squared
+// error of a step is reduced together with the normal equations of the next
+// one (one reduction per iteration for point_to_line); its convergence test
+// therefore arrives one search late, and the totals it returns are the ones
+// held back from before that search — the reference's results exactly.
+//
+// Pairs that do not fit (more than 4 rows per thread, target larger than the
+// LDS copy, 3-D) run on the exhaustive kernel of icp.hip.
 #include <cstdlib>
 
 #include "linalg.hpp"
 #include "sweep.hpp"
 
-// -DICPMI_DIAG: a diagnostic build that accumulates s_memtime cycles per phase of
-// the iteration in thread 0 and stores them in the unused R slots 4..8 of the
-// result record (2-D uses 0..3).  Never part of the shipped library.
+// -DICPMI_DIAG: diagnostic build; thread 0 accumulates s_memtime cycles per phase
+// and stores them in the unused R slots 4..8 of its result record.  Never shipped.
 #ifdef ICPMI_DIAG
 #define DIAG_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define DIAG_SET(var) var = __builtin_readcyclecounter()
 #define DIAG_ADD(acc, a, b) acc += (double)((b) - (a))
 #else
 #define DIAG_T(var)
+#define DIAG_SET(var)
 #define DIAG_ADD(acc, a, b)
 #endif
 
 namespace icpmi {
 
-constexpr int ICP2_SMAX = 4;
 
 struct Icp2Args {
     const double* pts;
@@ -49,19 +60,46 @@ struct Icp2Args {
     int has_init;
 };
 
-template <int THREADS>
+// Two-level workgroup sum that keeps the many waves cheap: every wave only sums
+// inside its 16-lane rows (4 DPP steps per value) and stores one partial per row,
+// scratch[i*64 + 4*wave + row]; the lead wave then adds the 64 partials of each
+// value (slots of absent waves stay zero).  Fixed trees: reproducible.
+template <int NV>
+__device__ __forceinline__ void store_partials(double* scratch, const double (&v)[NV]) {
+    const int w = wave_id(), l = lane_id();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double s = row_sum(v[i]);
+        if ((l & 15) == 0) scratch[i * 64 + 4 * w + (l >> 4)] = s;
+    }
+}
+
+template <int NV>
+__device__ __forceinline__ void combine_partials(const double* scratch, double (&v)[NV]) {
+    const int l = lane_id();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(scratch[i * 64 + l]);
+}
+
+template <int NV>
+constexpr int partial_doubles() { return NV * 64; }
+
+// control block published by wave 0: r (4), t (2), stop flag, mean_p (2), mean_q (2)
+constexpr int CTRL_R = 0, CTRL_T = 4, CTRL_STOP = 6, CTRL_MP = 8, CTRL_MQ = 10, CTRL_DOUBLES = 12;
+
+// THREADS x ICP2_SMAX = most source rows a pair may have on this instantiation
+template <int THREADS, int ICP2_SMAX>
 __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   // 4 waves/SIMD: 2 x 512 or 1 x 1024 per CU
-    constexpr int MAXW = THREADS / ICPMI_WAVE;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    __shared__ double redA[block_sum_doubles<10>()];   // normal equations / centroids
-    __shared__ double redB[block_sum_doubles<4>()];    // cross-covariance
-    __shared__ double redC[block_sum_doubles<1>()];    // squared error
-    block_sum_init(redA, block_sum_doubles<10>());
-    block_sum_init(redB, block_sum_doubles<4>());
-    block_sum_init(redC, block_sum_doubles<1>());
+    __shared__ double redA[partial_doubles<11>()];     // normal equations (10) / centroid sums (5) + carried squared error
+    __shared__ double redB[partial_doubles<4>()];      // cross-covariance
+    __shared__ double ctrl[CTRL_DOUBLES];
+    block_sum_init(redA, partial_doubles<11>());
+    block_sum_init(redB, partial_doubles<4>());
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    const bool lead = tid < ICPMI_WAVE;                      // wave 0 carries the uniform state
     const int sc = a.pair_src[b], tc = a.pair_tgt[b];
     const int N = a.cnt ? a.cnt[sc] : a.off[sc + 1] - a.off[sc];
     const int M = a.cnt ? a.cnt[tc] : a.off[tc + 1] - a.off[tc];
@@ -99,11 +137,22 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
         // moving source rows in registers: row n = s*THREADS + tid
         double px[ICP2_SMAX], py[ICP2_SMAX], d2[ICP2_SMAX];
         int pos[ICP2_SMAX];
+        // Movement budget of each row's match.  A search also returns the distance
+        // of the second nearest target point; while the row is displaced from where
+        // it was searched (the anchor) by less than half the gap between the two
+        // distances, no other target point can have become nearest (triangle
+        // inequality), so the match is kept and only its distance is re-evaluated.
+        // Exact: margins cover rounding; on a tie the budget is <= 0 and the search
+        // runs again.  Net displacement, so a pair that oscillates in a limit cycle
+        // (the usual reason for running to max_iterations) stops searching too.
+        double ax[ICP2_SMAX], ay[ICP2_SMAX], budget[ICP2_SMAX];
+#pragma unroll
+        for (int s = 0; s < ICP2_SMAX; ++s) { ax[s] = 0.0; ay[s] = 0.0; budget[s] = -1.0; }
         const int S = (N + THREADS - 1) / THREADS;
 #pragma unroll
         for (int s = 0; s < ICP2_SMAX; ++s) {
             const int n = s * THREADS + tid;
-            px[s] = 0.0; py[s] = 0.0; d2[s] = 0.0; pos[s] = 0;
+            px[s] = 0.0; py[s] = 0.0; d2[s] = 0.0; pos[s] = -1;          // -1: no previous match yet
             if (n < N) {
                 const double x = src[2 * n], y = src[2 * n + 1];
                 if (a.has_init) {                           // source @ R_init.T + t_init
@@ -121,33 +170,60 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
         // largest |projection| of the target (the copy is sorted along it): rounding slack of the diagonal axes
         const double2 c_lo = sxy[0], c_hi = sxy[M - 1];
         const double uabs = fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y)));
-#pragma unroll
-        for (int s = 0; s < ICP2_SMAX; ++s) pos[s] = -1;                 // no previous match yet
 
+        double e_part = 0.0;          // this thread's share of the squared error of the step just applied
+        bool stopped = false;
 #ifdef ICPMI_DIAG
-        double dg_nn = 0, dg_acc = 0, dg_apply = 0, dg_gather = 0, dg_red = 0, dg_solve = 0;
+        double dg_nn = 0, dg_red = 0, dg_lead = 0, dg_apply = 0;
 #endif
         for (int it = 0; it < a.max_iterations; ++it) {
             DIAG_T(c0);
             // ── correspondences: exact sweep search in LDS, icp.py:179 ───────
 #pragma unroll
             for (int s = 0; s < ICP2_SMAX; ++s)
-                if (s < S && s * THREADS + tid < N) pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], d2[s]);
+                if (s < S && s * THREADS + tid < N) {
+                    // |dx| + |dy| >= the distance between the row and its anchor
+                    if ((fabs(px[s] - ax[s]) + fabs(py[s] - ay[s])) * 1.000000001 < budget[s]) {   // match provably unchanged
+                        const double2 c = sxy[pos[s]];
+                        const double dx = px[s] - c.x, dy = py[s] - c.y;
+                        double q2 = 0.0;
+                        q2 += dx * dx;
+                        q2 += dy * dy;
+                        d2[s] = q2;
+                    } else {
+                        double second;
+                        pos[s] = sweep_nn2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], d2[s], second);
+                        const double d1 = sqrt(d2[s]), ds = sqrt(second);
+                        budget[s] = second < __builtin_inf() ? (ds - d1) * 0.4999999995 - 1e-13 * (ds + d1)
+                                                              : __builtin_inf();
+                        ax[s] = px[s]; ay[s] = py[s];
+#ifdef ICPMI_DIAG
+                        atomicAdd(&res[8], 1.0);             // diag: number of searches run by this pair
+#endif
+                    }
+                }
 #ifdef ICPMI_DIAG
             __syncthreads();          // diag only: charge the slowest wave's search to the search phase
 #endif
             DIAG_T(c1);
-            double r[4], t[2];
+#ifdef ICPMI_DIAG
+            unsigned long long c2 = 0;
+#endif
+            bool in[ICP2_SMAX];
+#pragma unroll
+            for (int s = 0; s < ICP2_SMAX; ++s) {
+                in[s] = s < S && s * THREADS + tid < N;
+                if (in[s] && has_corr) {                                          // icp.py:184-185
+                    const double dist = sqrt(d2[s]);
+                    in[s] = dist * dist < max_corr_sq;
+                }
+            }
             if (use_p2l) {
-                // ── point-to-line normal equations, icp.py:88-104 ────────────
-                double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                // ── point-to-line normal equations, icp.py:88-104, + carried error ─
+                double acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < ICP2_SMAX; ++s) {
-                    if (!(s < S && s * THREADS + tid < N)) continue;
-                    if (has_corr) {                                               // icp.py:184-185
-                        const double dist = sqrt(d2[s]);
-                        if (!(dist * dist < max_corr_sq)) continue;
-                    }
+                    if (!in[s]) continue;
                     const double2 q = sxy[pos[s]], nm = snrm[pos[s]];
                     const double dx = px[s] - q.x, dy = py[s] - q.y;
                     const double c = nm.y * px[s] - nm.x * py[s];
@@ -157,102 +233,147 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                     acc[6] += c * bi;      acc[7] += nm.x * bi;   acc[8] += nm.y * bi;
                     acc[9] += 1.0;
                 }
-                DIAG_T(d0);
-                block_sum<10, MAXW>(acc, redA);
-                DIAG_T(d1);
-                if (has_corr && acc[9] < (double)need) { status = ICPMI_ST_FEW_INLIERS; break; }
-                double A[3][3] = {{acc[0], acc[1], acc[2]}, {acc[1], acc[3], acc[4]}, {acc[2], acc[4], acc[5]}};
-                double rhs[3] = {acc[6], acc[7], acc[8]}, x[3];
-                if (solve3(A, rhs, x)) {
-                    double st, ct;
-                    sincos(x[0], &st, &ct);                                        // icp.py:110-114
-                    r[0] = ct; r[1] = -st; r[2] = st; r[3] = ct; t[0] = x[1]; t[1] = x[2];
-                } else {
-                    r[0] = 1.0; r[1] = 0.0; r[2] = 0.0; r[3] = 1.0; t[0] = 0.0; t[1] = 0.0;
+                acc[10] = e_part;
+                store_partials<11>(redA, acc);
+                __syncthreads();
+                DIAG_SET(c2);
+                if (lead) {
+                    combine_partials<11>(redA, acc);
+                    bool stop = false;
+                    if (it > 0) {                                                  // finish step it-1: icp.py:215-220
+                        err = acc[10] / (double)N;
+                        iters = it;
+                        delta = fabs(prev - err);
+                        if (delta < a.error_threshold) { status = ICPMI_ST_CONVERGED; stop = true; }
+                        prev = err;
+                    }
+                    if (!stop && has_corr && acc[9] < (double)need) { status = ICPMI_ST_FEW_INLIERS; iters = it; stop = true; }
+                    if (!stop) {
+                        double A[3][3] = {{acc[0], acc[1], acc[2]}, {acc[1], acc[3], acc[4]}, {acc[2], acc[4], acc[5]}};
+                        double rhs[3] = {acc[6], acc[7], acc[8]}, x[3];
+                        double r[4], t[2];
+                        if (solve3(A, rhs, x)) {
+                            double st, ct;
+                            sincos_step(x[0], st, ct);                             // icp.py:110-114
+                            r[0] = ct; r[1] = -st; r[2] = st; r[3] = ct; t[0] = x[1]; t[1] = x[2];
+                        } else {
+                            r[0] = 1.0; r[1] = 0.0; r[2] = 0.0; r[3] = 1.0; t[0] = 0.0; t[1] = 0.0;
+                        }
+                        // accumulate totals, icp.py:210-211
+                        const double n0 = r[0] * rt[0] + r[1] * rt[2], n1 = r[0] * rt[1] + r[1] * rt[3];
+                        const double n2 = r[2] * rt[0] + r[3] * rt[2], n3 = r[2] * rt[1] + r[3] * rt[3];
+                        const double u0 = (tt[0] * r[0] + tt[1] * r[1]) + t[0], u1 = (tt[0] * r[2] + tt[1] * r[3]) + t[1];
+                        rt[0] = n0; rt[1] = n1; rt[2] = n2; rt[3] = n3; tt[0] = u0; tt[1] = u1;
+                        if (tid == 0) {
+                            ctrl[CTRL_R] = r[0]; ctrl[CTRL_R + 1] = r[1]; ctrl[CTRL_R + 2] = r[2]; ctrl[CTRL_R + 3] = r[3];
+                            ctrl[CTRL_T] = t[0]; ctrl[CTRL_T + 1] = t[1];
+                        }
+                    }
+                    if (tid == 0) ctrl[CTRL_STOP] = stop ? 1.0 : 0.0;
                 }
-#ifdef ICPMI_DIAG
-                DIAG_T(d2);
-                DIAG_ADD(dg_gather, c1, d0); DIAG_ADD(dg_red, d0, d1); DIAG_ADD(dg_solve, d1, d2);
-                if (tid == 0) { res[7] = dg_gather; res[8] = dg_red; res[10 + 1] = dg_solve; }
-#endif
+                __syncthreads();
             } else {
-                // ── point-to-point: centroids, centred cross-covariance, icp.py:197-207 ─
-                double m[5] = {0, 0, 0, 0, 0};
+                // ── point-to-point: centroids (+ carried error), icp.py:197-198 ──
+                double m[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < ICP2_SMAX; ++s) {
-                    if (!(s < S && s * THREADS + tid < N)) continue;
-                    if (has_corr) {
-                        const double dist = sqrt(d2[s]);
-                        if (!(dist * dist < max_corr_sq)) continue;
-                    }
+                    if (!in[s]) continue;
                     const double2 q = sxy[pos[s]];
                     m[0] += px[s]; m[1] += py[s]; m[2] += q.x; m[3] += q.y; m[4] += 1.0;
                 }
-                block_sum<5, MAXW>(m, redA);
-                if (has_corr && m[4] < (double)need) { status = ICPMI_ST_FEW_INLIERS; break; }
-                const double mpx = m[0] / m[4], mpy = m[1] / m[4], mqx = m[2] / m[4], mqy = m[3] / m[4];
+                m[5] = e_part;
+                store_partials<6>(redA, m);
+                __syncthreads();
+                DIAG_SET(c2);
+                if (lead) {
+                    combine_partials<6>(redA, m);
+                    bool stop = false;
+                    if (it > 0) {
+                        err = m[5] / (double)N;
+                        iters = it;
+                        delta = fabs(prev - err);
+                        if (delta < a.error_threshold) { status = ICPMI_ST_CONVERGED; stop = true; }
+                        prev = err;
+                    }
+                    if (!stop && has_corr && m[4] < (double)need) { status = ICPMI_ST_FEW_INLIERS; iters = it; stop = true; }
+                    if (tid == 0) {
+                        ctrl[CTRL_STOP] = stop ? 1.0 : 0.0;
+                        ctrl[CTRL_MP] = m[0] / m[4]; ctrl[CTRL_MP + 1] = m[1] / m[4];
+                        ctrl[CTRL_MQ] = m[2] / m[4]; ctrl[CTRL_MQ + 1] = m[3] / m[4];
+                    }
+                }
+                __syncthreads();
+                if (ctrl[CTRL_STOP] != 0.0) { stopped = true; break; }
+                const double mpx = ctrl[CTRL_MP], mpy = ctrl[CTRL_MP + 1], mqx = ctrl[CTRL_MQ], mqy = ctrl[CTRL_MQ + 1];
+                // centred cross-covariance, icp.py:199-201
                 double W[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int s = 0; s < ICP2_SMAX; ++s) {
-                    if (!(s < S && s * THREADS + tid < N)) continue;
-                    if (has_corr) {
-                        const double dist = sqrt(d2[s]);
-                        if (!(dist * dist < max_corr_sq)) continue;
-                    }
+                    if (!in[s]) continue;
                     const double2 q = sxy[pos[s]];
                     const double pcx = px[s] - mpx, pcy = py[s] - mpy, qcx = q.x - mqx, qcy = q.y - mqy;
                     W[0] += pcx * qcx; W[1] += pcx * qcy; W[2] += pcy * qcx; W[3] += pcy * qcy;
                 }
-                block_sum<4, MAXW>(W, redB);
-                kabsch2(W, r);
-                double s0 = 0.0, s1 = 0.0;
-                s0 += r[0] * mpx; s0 += r[1] * mpy;
-                s1 += r[2] * mpx; s1 += r[3] * mpy;
-                t[0] = mqx - s0; t[1] = mqy - s1;                                  // icp.py:207
-            }
-            DIAG_T(c2);
-            // ── accumulate totals, icp.py:210-211 ────────────────────────────
-            {
-                double nr[4], nt[2];
-                for (int i = 0; i < 2; ++i) {
-                    for (int k = 0; k < 2; ++k) {
-                        double s = 0.0;
-                        for (int c = 0; c < 2; ++c) s += r[i * 2 + c] * rt[c * 2 + k];
-                        nr[i * 2 + k] = s;
+                store_partials<4>(redB, W);
+                __syncthreads();
+                if (lead) {
+                    combine_partials<4>(redB, W);
+                    double r[4], t[2];
+                    kabsch2(W, r);                                                 // icp.py:202-206
+                    double s0 = 0.0, s1 = 0.0;
+                    s0 += r[0] * mpx; s0 += r[1] * mpy;
+                    s1 += r[2] * mpx; s1 += r[3] * mpy;
+                    t[0] = mqx - s0; t[1] = mqy - s1;                              // icp.py:207
+                    const double n0 = r[0] * rt[0] + r[1] * rt[2], n1 = r[0] * rt[1] + r[1] * rt[3];
+                    const double n2 = r[2] * rt[0] + r[3] * rt[2], n3 = r[2] * rt[1] + r[3] * rt[3];
+                    const double u0 = (tt[0] * r[0] + tt[1] * r[1]) + t[0], u1 = (tt[0] * r[2] + tt[1] * r[3]) + t[1];
+                    rt[0] = n0; rt[1] = n1; rt[2] = n2; rt[3] = n3; tt[0] = u0; tt[1] = u1;
+                    if (tid == 0) {
+                        ctrl[CTRL_R] = r[0]; ctrl[CTRL_R + 1] = r[1]; ctrl[CTRL_R + 2] = r[2]; ctrl[CTRL_R + 3] = r[3];
+                        ctrl[CTRL_T] = t[0]; ctrl[CTRL_T + 1] = t[1];
                     }
-                    double s = 0.0;
-                    for (int k = 0; k < 2; ++k) s += tt[k] * r[i * 2 + k];
-                    nt[i] = s + t[i];
                 }
-                rt[0] = nr[0]; rt[1] = nr[1]; rt[2] = nr[2]; rt[3] = nr[3]; tt[0] = nt[0]; tt[1] = nt[1];
+                __syncthreads();
             }
-            // ── apply to ALL rows, mean squared residual, icp.py:212-215 ─────
-            double e[1] = {0.0};
+            DIAG_T(c3);
+            if (ctrl[CTRL_STOP] != 0.0) { stopped = true; break; }
+            // ── apply to ALL rows; squared residual against this search's matches, icp.py:212-215 ─
+            const double r0 = ctrl[CTRL_R], r1 = ctrl[CTRL_R + 1], r2 = ctrl[CTRL_R + 2], r3 = ctrl[CTRL_R + 3];
+            const double t0 = ctrl[CTRL_T], t1 = ctrl[CTRL_T + 1];
+            e_part = 0.0;
 #pragma unroll
             for (int s = 0; s < ICP2_SMAX; ++s) {
                 if (!(s < S && s * THREADS + tid < N)) continue;
                 const double2 q = sxy[pos[s]];
                 double nx = 0.0, ny = 0.0;
-                nx += px[s] * r[0]; nx += py[s] * r[1]; nx += t[0];
-                ny += px[s] * r[2]; ny += py[s] * r[3]; ny += t[1];
+                nx += px[s] * r0; nx += py[s] * r1; nx += t0;
+                ny += px[s] * r2; ny += py[s] * r3; ny += t1;
                 px[s] = nx; py[s] = ny;
                 const double ex = q.x - nx, ey = q.y - ny;
                 double se = 0.0;
                 se += ex * ex;
                 se += ey * ey;
-                e[0] += se;
+                e_part += se;
             }
-            block_sum<1, MAXW>(e, redC);
-            DIAG_T(c3);
+            DIAG_T(c4);
 #ifdef ICPMI_DIAG
-            DIAG_ADD(dg_nn, c0, c1); DIAG_ADD(dg_acc, c1, c2); DIAG_ADD(dg_apply, c2, c3);
-            if (tid == 0) { res[4] = dg_nn; res[5] = dg_acc; res[6] = dg_apply; }
+            DIAG_ADD(dg_nn, c0, c1); DIAG_ADD(dg_red, c1, c2); DIAG_ADD(dg_lead, c2, c3); DIAG_ADD(dg_apply, c3, c4);
+            if (tid == 0) { res[4] = dg_nn; res[5] = dg_red; res[6] = dg_lead; res[7] = dg_apply; }
 #endif
-            err = e[0] / (double)N;
-            iters = it + 1;
-            delta = fabs(prev - err);
-            if (delta < a.error_threshold) { status = ICPMI_ST_CONVERGED; break; }   // icp.py:216-219
-            prev = err;
+        }
+        if (!stopped && a.max_iterations > 0) {
+            // the last step's error has not been reduced yet: icp.py:215-223 for it = max_iterations - 1
+            double e[1] = {e_part};
+            __syncthreads();                      // redA may still be read by the lead wave of the last iteration
+            store_partials<1>(redA, e);
+            __syncthreads();
+            if (lead) {
+                combine_partials<1>(redA, e);
+                err = e[0] / (double)N;
+                iters = a.max_iterations;
+                delta = fabs(prev - err);
+                if (delta < a.error_threshold) status = ICPMI_ST_CONVERGED;
+            }
         }
     }
     if (tid == 0) {
@@ -286,17 +407,20 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     a.error_threshold = p->error_threshold; a.max_corr_dist = p->max_corr_dist;
     a.max_iterations = p->max_iterations; a.method = p->method; a.has_init = p->has_init;
     const size_t lds = (size_t)cap * 36;
-    // rows per thread: 1024-thread workgroups once a source has more than 1024 rows (2 rows per thread
-    // instead of 3-4 shortens the search phase, which is the critical path of a pair)
+    // Workgroup shape by source size (rows per thread bounded by the instantiation).  ICPMI_ICP2_THREADS
+    // (512 / 1024) overrides the thread count for experiments.
     const char* env = getenv("ICPMI_ICP2_THREADS");
-    const int want = env ? atoi(env) : (max_src_n > 1024 ? 1024 : 512);
-    if (want != 1024 && max_src_n <= 512 * ICP2_SMAX) {
-        if (hipFuncSetAttribute((const void*)icp2_fused_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP;
-        icp2_fused_kernel<512><<<n_pairs, 512, lds, st>>>(a);
-    } else {
-        if (hipFuncSetAttribute((const void*)icp2_fused_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP;
-        icp2_fused_kernel<1024><<<n_pairs, 1024, lds, st>>>(a);
-    }
+    const int want = env ? atoi(env) : 0;
+#define ICPMI_ICP2_GO(T, SM)                                                                                                     \
+    do {                                                                                                                         \
+        if (hipFuncSetAttribute((const void*)icp2_fused_kernel<T, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
+            hipSuccess) return ICPMI_ERR_HIP;                                                                                    \
+        icp2_fused_kernel<T, SM><<<n_pairs, T, lds, st>>>(a);                                                                    \
+    } while (0)
+    if (want == 512 && max_src_n <= 2048) { if (max_src_n <= 1024) ICPMI_ICP2_GO(512, 2); else ICPMI_ICP2_GO(512, 4); }
+    else if (want == 1024 || max_src_n > 1024) { if (max_src_n <= 2048) ICPMI_ICP2_GO(1024, 2); else ICPMI_ICP2_GO(1024, 4); }
+    else ICPMI_ICP2_GO(512, 2);
+#undef ICPMI_ICP2_GO
     ICPMI_LAUNCH_CHECK();
     return ICPMI_OK;
 }

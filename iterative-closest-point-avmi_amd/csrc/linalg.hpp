@@ -39,6 +39,38 @@ __device__ __forceinline__ bool solve3(double (&A)[3][3], double (&b)[3], double
     return true;
 }
 
+// sin and cos of the point-to-line angle (icp.py:110-111).  |theta| is small in
+// any converging registration: the Taylor series to x^19 / x^18 is exact to
+// double rounding below 0.25 rad and costs ~25 multiply-adds instead of the
+// library's argument reduction; larger angles take the library path.
+__device__ __forceinline__ void sincos_step(double x, double& s, double& c) {
+    if (fabs(x) < 0.25) {
+        const double z = x * x;
+        double ps = -1.0 / 121645100408832000.0;                 // -1/19!
+        ps = ps * z + 1.0 / 355687428096000.0;                   //  1/17!
+        ps = ps * z - 1.0 / 1307674368000.0;                     // -1/15!
+        ps = ps * z + 1.0 / 6227020800.0;                        //  1/13!
+        ps = ps * z - 1.0 / 39916800.0;                          // -1/11!
+        ps = ps * z + 1.0 / 362880.0;                            //  1/9!
+        ps = ps * z - 1.0 / 5040.0;                              // -1/7!
+        ps = ps * z + 1.0 / 120.0;                               //  1/5!
+        ps = ps * z - 1.0 / 6.0;                                 // -1/3!
+        s = x + x * (z * ps);
+        double pc = 1.0 / 6402373705728000.0;                    //  1/18!
+        pc = pc * z - 1.0 / 20922789888000.0;                    // -1/16!
+        pc = pc * z + 1.0 / 87178291200.0;                       //  1/14!
+        pc = pc * z - 1.0 / 479001600.0;                         // -1/12!
+        pc = pc * z + 1.0 / 3628800.0;                           //  1/10!
+        pc = pc * z - 1.0 / 40320.0;                             // -1/8!
+        pc = pc * z + 1.0 / 720.0;                               //  1/6!
+        pc = pc * z - 1.0 / 24.0;                                // -1/4!
+        pc = pc * z + 0.5;                                       //  1/2!
+        c = 1.0 - z * pc;
+    } else {
+        sincos(x, &s, &c);
+    }
+}
+
 // Optimal proper rotation for the 2x2 cross-covariance W = sum pc qc^T: what
 // r = V U^T with the det<0 fix evaluates to (reference icp.py:202-206).
 // tr(R W) = c (W00+W11) + s (W01-W10) is maximal at (c, s) parallel to those.

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(P2L_THREADS) void p2l_solve_kernel(
         double A[3][3] = {{acc[0], acc[1], acc[2]}, {acc[1], acc[3], acc[4]}, {acc[2], acc[4], acc[5]}};
         double rhs[3] = {acc[6], acc[7], acc[8]}, x[3];
         if (solve3(A, rhs, x)) {
-            const double ct = cos(x[0]), st = sin(x[0]);
+            double st, ct;
+            sincos_step(x[0], st, ct);
             out[0] = ct; out[1] = -st; out[2] = st; out[3] = ct; out[4] = x[1]; out[5] = x[2];
         } else {                                      // icp.py:107-108
             out[0] = 1.0; out[1] = 0.0; out[2] = 0.0; out[3] = 1.0; out[4] = 0.0; out[5] = 0.0;

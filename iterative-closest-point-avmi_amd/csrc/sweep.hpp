@@ -53,6 +53,64 @@ __device__ __forceinline__ double prune_width(int dir, double best, double uq, d
     return sqrt(best * 2.000000000000002) * 1.0000000000000004 + 4.5e-16 * (fabs(uq) + uabs);
 }
 
+// The same search, also returning the squared distance of the SECOND nearest
+// target point (inf if the cloud has one point).  The window is the one of the
+// second-best distance, so nothing that could be first or second is skipped.
+// The gap between the two distances is what lets the caller keep a match for
+// later iterations without searching again (see icp2.hip, "movement budget").
+__device__ __forceinline__ int sweep_nn2(const double2* sxy, const int32_t* sorig, int m, int dir, double uabs,
+                                         double qx, double qy, int start, double& d2_out, double& second_out) {
+    const double uq = proj(dir, qx, qy);
+    double best = __builtin_inf(), second = __builtin_inf(), thr = __builtin_inf();
+    int bpos = 0, brow = 0x7fffffff;
+    int lo, hi;
+    if (start >= 0 && start < m) {
+        const double2 c = sxy[start];
+        const double dx = qx - c.x, dy = qy - c.y;
+        double s = 0.0;
+        s += dx * dx;
+        s += dy * dy;
+        best = s; bpos = start; brow = sorig[start];
+        lo = start - 1; hi = start + 1;
+    } else {
+        hi = sweep_lower_bound(sxy, m, dir, uq);
+        lo = hi - 1;
+    }
+    while (lo >= 0 || hi < m) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const bool right = side == 0;
+            if (right ? hi < m : lo >= 0) {
+                const int i = right ? hi : lo;
+                const double2 c = sxy[i];
+                const double du = right ? proj(dir, c.x, c.y) - uq : uq - proj(dir, c.x, c.y);
+                if (du > thr) { if (right) hi = m; else lo = -1; }      // everything further out is farther than `second`
+                else {
+                    if (du >= -thr) {
+                        const double dx = qx - c.x, dy = qy - c.y;
+                        double s = 0.0;
+                        s += dx * dx;
+                        s += dy * dy;
+                        if (s <= best) {                         // new winner, or an exact tie with it
+                            const int row = sorig[i];
+                            if (s < best || row < brow) { second = best; best = s; bpos = i; brow = row; }
+                            else second = s;                     // tie lost on the row: second == best
+                            thr = prune_width(dir, second, uq, uabs);
+                        } else if (s < second) {
+                            second = s;
+                            thr = prune_width(dir, second, uq, uabs);
+                        }
+                    }
+                    if (right) ++hi; else --lo;
+                }
+            }
+        }
+    }
+    d2_out = best;
+    second_out = second;
+    return bpos;
+}
+
 // 1-NN of (qx, qy) in the sorted cloud.  Returns the sorted position; d2 is the
 // squared distance; ties go to the lowest original row (sorig).  `start` >= 0 is
 // a position to start from (the previous iteration's match: it seeds the bound

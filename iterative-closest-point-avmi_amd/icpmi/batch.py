@@ -154,6 +154,37 @@ def nn_set(cs, pair_src, pair_tgt):
     return dist, idx
 
 
+def nn_set_sweep(cs, pair_src, pair_tgt, return_second=False):
+    """Same result as ``nn_set`` by the sorted-sweep search (2-D, target clouds of at most 4096 rows):
+    prepares the target clouds (axis choice + sort), then binary search + outward sweep per query."""
+    L = _lib.lib()
+    if cs.dim != 2:
+        raise ValueError("the sweep search is 2-D only")
+    dev = cs.pts.device
+    pair_src = np.ascontiguousarray(pair_src, dtype=np.int32)
+    pair_tgt = np.ascontiguousarray(pair_tgt, dtype=np.int32)
+    B = len(pair_src)
+    sizes = np.diff(cs.off_host)
+    tgt_ids = np.unique(pair_tgt)
+    max_tgt = int(sizes[tgt_ids].max()) if B else 0
+    if max_tgt > PREP_MAX_POINTS:
+        raise ValueError(f"target clouds above {PREP_MAX_POINTS} rows need the exhaustive search (nn_set)")
+    stride = max(int(sizes[pair_src].max()) if B else 0, 1)
+    prepared = torch.empty(L.icpmi_prepared_bytes(cs.total_rows, cs.n_clouds), dtype=torch.uint8, device=dev)
+    ids = torch.from_numpy(tgt_ids.astype(np.int32)).to(dev)
+    check(L.icpmi_prepare_targets(_ptr(cs.pts), _ptr(cs.off), _ptr(cs.cnt), _ptr(ids), len(tgt_ids), cs.n_clouds,
+                                  cs.total_rows, max_tgt, -1, None, _ptr(prepared), prepared.numel(), _stream()),
+          "prepare_targets")
+    ps, pt = torch.from_numpy(pair_src).to(dev), torch.from_numpy(pair_tgt).to(dev)
+    idx = torch.empty((max(B, 1), stride), dtype=torch.int32, device=dev)
+    dist = torch.empty((max(B, 1), stride), dtype=torch.float64, device=dev)
+    second = torch.empty((max(B, 1), stride), dtype=torch.float64, device=dev) if return_second else None
+    check(L.icpmi_nn_prepared_batch(_ptr(cs.pts), _ptr(cs.off), _ptr(cs.cnt), _ptr(prepared), _ptr(ps), _ptr(pt), B,
+                                    stride, max_tgt, cs.total_rows, _ptr(idx), _ptr(dist), _ptr(second), stride,
+                                    _stream()), "nn (sweep)")
+    return (dist, idx, second) if return_second else (dist, idx)
+
+
 class IcpBatch:
     """A batch of scan pairs resident in HBM, ready to be registered repeatedly.
 

@@ -348,24 +348,59 @@ def test_fast_path_equals_exhaustive_path(uicp):
         assert rot_err(R[i], t[i], Ro, to) < FRO_TOL and info["iters"][i] == io["iters"], i
 
 
-def test_sweep_nn_adversarial_layouts(uicp):
-    """Clouds that stress the sweep search: one vertical wall (all x equal), exact duplicates, far-away queries."""
+def test_sweep_nn_equals_exhaustive_nn(uicp):
+    """The sorted-sweep search (nn_sweep.hip, the search of the fused ICP kernel) must return the very same
+    index and float64 distance as the exhaustive kernel, on ordinary scans and on layouts built to stress it:
+    a wall perpendicular to every candidate axis in turn, exact duplicates (ties), queries far outside the
+    target, single-point and two-point targets, every size around the wave and tile edges."""
+    from icpmi import batch, synth
+    rng = np.random.default_rng(8)
+    wall_v = np.stack([np.full(900, 2.5), np.linspace(-5, 5, 900)], 1)
+    wall_d = np.stack([np.linspace(-5, 5, 900), np.linspace(5, -5, 900)], 1)        # x + y constant
+    dup = np.repeat(rng.uniform(-1, 1, size=(100, 2)), 5, axis=0)
+    grid = np.stack(np.meshgrid(np.arange(30.0), np.arange(30.0)), -1).reshape(-1, 2)  # many exact ties
+    a, b = synth.config2_pair(3)
+    cases = [(a, b), (b, a),
+             (wall_v + rng.normal(scale=1e-3, size=wall_v.shape), wall_v),
+             (rng.uniform(-6, 6, size=(777, 2)), wall_d), (wall_d + 0.5, wall_d @ np.array([[0.0, 1.0], [1.0, 0.0]])),
+             (dup + 0.01, dup), (dup, dup),
+             (grid + 0.5, grid), (grid, grid),
+             (rng.uniform(50, 60, size=(400, 2)), rng.uniform(-1, 1, size=(700, 2))),
+             (rng.uniform(-1, 1, size=(300, 2)), np.array([[0.25, -0.5]])),
+             (rng.uniform(-1, 1, size=(65, 2)), np.array([[0.25, -0.5], [0.25, -0.5]])),
+             (rng.uniform(-1e6, 1e6, size=(1000, 2)), rng.uniform(-1e6, 1e6, size=(4096, 2))),
+             (rng.uniform(-1, 1, size=(1, 2)), rng.uniform(-1, 1, size=(63, 2)))]
+    clouds, ps, pt = [], [], []
+    for s, t in cases:
+        ps.append(len(clouds)); clouds.append(s)
+        pt.append(len(clouds)); clouds.append(t)
+    cs = batch.CloudSet.from_numpy(clouds)
+    d0, i0 = batch.nn_set(cs, ps, pt)
+    d1, i1, s1 = batch.nn_set_sweep(cs, ps, pt, return_second=True)
+    d0, i0, d1, i1, s1 = (x.cpu().numpy() for x in (d0, i0, d1, i1, s1))
+    for k, (s, t) in enumerate(cases):
+        n = len(s)
+        assert np.array_equal(i0[k, :n], i1[k, :n]), k
+        assert np.array_equal(d0[k, :n], d1[k, :n]), k
+        if len(t) >= 2:      # second-best distance against the oracle's 2-NN
+            d2o, _ = oracle.knn(t, s, 2)
+            assert np.array_equal(s1[k, :n], d2o[:, 1]), k
+        else:
+            assert np.all(np.isinf(s1[k, :n]))
+
+
+def test_icp_on_degenerate_layouts_runs(uicp):
+    """Single wall / duplicates / no overlap: ill-posed for ICP (results are not comparable between
+    implementations), but both kernels must terminate with a valid status and finite bookkeeping."""
     from icpmi import batch
     rng = np.random.default_rng(8)
     wall = np.stack([np.full(900, 2.5), np.linspace(-5, 5, 900)], 1)
     dup = np.repeat(rng.uniform(-1, 1, size=(100, 2)), 5, axis=0)
-    cases = [(wall + rng.normal(scale=1e-3, size=wall.shape), wall),
-             (dup + 0.01, dup),
+    cases = [(wall + rng.normal(scale=1e-3, size=wall.shape), wall), (dup + 0.01, dup),
              (rng.uniform(50, 60, size=(400, 2)), rng.uniform(-1, 1, size=(700, 2)))]
-    # These geometries are degenerate for ICP itself (a single wall lets the solution slide), so the
-    # check is between the two search strategies, which share every other instruction: equal
-    # correspondences give equal iterates.
     for src, tgt in cases:
         for method in ("point_to_point", "point_to_line"):
-            kw = dict(method=method, normal_k=6)
-            f = batch.IcpBatch([src, tgt], [0], [1], 1e-12, 30, 1e-4, **kw)
-            e = batch.IcpBatch([src, tgt], [0], [1], 1e-12, 30, 1e-4, force_exhaustive=True, **kw)
-            f.run(); e.run()
-            rf, re_ = f.results.cpu().numpy()[0], e.results.cpu().numpy()[0]
-            assert rf[14] == re_[14] and rf[15] == re_[15], (rf[14:], re_[14:])
-            assert np.allclose(rf[:13], re_[:13], rtol=0, atol=1e-9 * max(1.0, np.abs(re_[:13]).max()))
+            for force in (False, True):
+                R, t, err, info = batch.icp_batch([src], [tgt], 1e-12, 30, 1e-4, method=method, normal_k=6,
+                                                  force_exhaustive=force)
+                assert info["status"][0] in (1, 2) and 1 <= info["iters"][0] <= 30
