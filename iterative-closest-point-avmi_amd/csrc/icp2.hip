@@ -94,6 +94,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
     __shared__ double redA[partial_doubles<11>()];     // normal equations (10) / centroid sums (5) + carried squared error
     __shared__ double redB[partial_doubles<4>()];      // cross-covariance
     __shared__ double ctrl[CTRL_DOUBLES];
+    __shared__ double totals[12];
     block_sum_init(redA, partial_doubles<11>());
     block_sum_init(redB, partial_doubles<4>());
 
@@ -137,17 +138,19 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
         // moving source rows in registers: row n = s*THREADS + tid
         double px[ICP2_SMAX], py[ICP2_SMAX], d2[ICP2_SMAX];
         int pos[ICP2_SMAX];
-        // Movement budget of each row's match.  A search also returns the distance
-        // of the second nearest target point; while the row is displaced from where
-        // it was searched (the anchor) by less than half the gap between the two
-        // distances, no other target point can have become nearest (triangle
-        // inequality), so the match is kept and only its distance is re-evaluated.
-        // Exact: margins cover rounding; on a tie the budget is <= 0 and the search
-        // runs again.  Net displacement, so a pair that oscillates in a limit cycle
-        // (the usual reason for running to max_iterations) stops searching too.
+        // Movement budget of each row's match.  A search returns the two nearest
+        // target points and the distance d3 of the third.  While the row is
+        // displaced from where it was searched (the anchor) by less than
+        // (d3 - d1)/2, every other target point is still farther than the nearer
+        // of those two (triangle inequality), so the match is the better of the
+        // two — two distance evaluations instead of a search.  Exact: margins cover
+        // rounding, equal distances fall back on the row rule or on a new search.
+        // Net displacement, so a pair that oscillates in a limit cycle (the usual
+        // reason for running to max_iterations) stops searching too.
         double ax[ICP2_SMAX], ay[ICP2_SMAX], budget[ICP2_SMAX];
+        int pos2[ICP2_SMAX];
 #pragma unroll
-        for (int s = 0; s < ICP2_SMAX; ++s) { ax[s] = 0.0; ay[s] = 0.0; budget[s] = -1.0; }
+        for (int s = 0; s < ICP2_SMAX; ++s) { ax[s] = 0.0; ay[s] = 0.0; budget[s] = -1.0; pos2[s] = -1; }
         const int S = (N + THREADS - 1) / THREADS;
 #pragma unroll
         for (int s = 0; s < ICP2_SMAX; ++s) {
@@ -183,19 +186,33 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
             for (int s = 0; s < ICP2_SMAX; ++s)
                 if (s < S && s * THREADS + tid < N) {
                     // |dx| + |dy| >= the distance between the row and its anchor
-                    if ((fabs(px[s] - ax[s]) + fabs(py[s] - ay[s])) * 1.000000001 < budget[s]) {   // match provably unchanged
+                    if ((fabs(px[s] - ax[s]) + fabs(py[s] - ay[s])) * 1.000000001 < budget[s]) {   // match is one of the two kept
                         const double2 c = sxy[pos[s]];
                         const double dx = px[s] - c.x, dy = py[s] - c.y;
                         double q2 = 0.0;
                         q2 += dx * dx;
                         q2 += dy * dy;
+                        if (pos2[s] >= 0) {
+                            const double2 e = sxy[pos2[s]];
+                            const double ex = px[s] - e.x, ey = py[s] - e.y;
+                            double w2 = 0.0;
+                            w2 += ex * ex;
+                            w2 += ey * ey;
+                            if (w2 < q2 || (w2 == q2 && sorig[pos2[s]] < sorig[pos[s]])) {
+                                const int tp = pos[s]; pos[s] = pos2[s]; pos2[s] = tp;
+                                q2 = w2;
+                            }
+                        }
                         d2[s] = q2;
+                    } else if (it < 2) {
+                        // the first steps move every row by more than any budget: plain 1-NN (smallest window)
+                        pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], d2[s]);
                     } else {
-                        double second;
-                        pos[s] = sweep_nn2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], d2[s], second);
-                        const double d1 = sqrt(d2[s]), ds = sqrt(second);
-                        budget[s] = second < __builtin_inf() ? (ds - d1) * 0.4999999995 - 1e-13 * (ds + d1)
-                                                              : __builtin_inf();
+                        const Top2 t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s]);
+                        pos[s] = t2.p1; pos2[s] = t2.p2; d2[s] = t2.s1;
+                        const double d1 = sqrt(t2.s1), d3 = sqrt(t2.s3);
+                        budget[s] = t2.s3 < __builtin_inf() ? (d3 - d1) * 0.4999999995 - 1e-13 * (d3 + d1)
+                                                             : __builtin_inf();
                         ax[s] = px[s]; ay[s] = py[s];
 #ifdef ICPMI_DIAG
                         atomicAdd(&res[8], 1.0);             // diag: number of searches run by this pair
@@ -236,9 +253,17 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                 acc[10] = e_part;
                 store_partials<11>(redA, acc);
                 __syncthreads();
+                // the 11 sums of 64 partials are spread over the waves (one value each), so the
+                // serial lead section only reads 11 totals
+                for (int i = wave_id(); i < 11; i += THREADS / ICPMI_WAVE) {
+                    const double tsum = wave_sum(redA[i * 64 + lane_id()]);
+                    if (lane_id() == 0) totals[i] = tsum;
+                }
+                __syncthreads();
                 DIAG_SET(c2);
                 if (lead) {
-                    combine_partials<11>(redA, acc);
+#pragma unroll
+                    for (int i = 0; i < 11; ++i) acc[i] = totals[i];
                     bool stop = false;
                     if (it > 0) {                                                  // finish step it-1: icp.py:215-220
                         err = acc[10] / (double)N;

@@ -31,15 +31,14 @@ struct TopKP {
     template <int I>
     __device__ __forceinline__ void bubble() {
         if constexpr (I > 0) {
-            const bool lt = d[I] < d[I - 1] || (d[I] == d[I - 1] && j[I] < j[I - 1]);
-            const double td = lt ? d[I - 1] : d[I];
-            const int tj = lt ? j[I - 1] : j[I];
-            const int tp = lt ? p[I - 1] : p[I];
-            d[I - 1] = lt ? d[I] : d[I - 1];
-            j[I - 1] = lt ? j[I] : j[I - 1];
-            p[I - 1] = lt ? p[I] : p[I - 1];
-            d[I] = td; j[I] = tj; p[I] = tp;
-            bubble<I - 1>();
+            // stop as soon as the new entry is in place: candidates arrive roughly by
+            // increasing distance, so most insertions move one or two slots
+            if (d[I] < d[I - 1] || (d[I] == d[I - 1] && j[I] < j[I - 1])) {
+                const double td = d[I - 1]; const int tj = j[I - 1], tp = p[I - 1];
+                d[I - 1] = d[I]; j[I - 1] = j[I]; p[I - 1] = p[I];
+                d[I] = td; j[I] = tj; p[I] = tp;
+                bubble<I - 1>();
+            }
         }
     }
     __device__ __forceinline__ void push(double s, int row, int pos) {

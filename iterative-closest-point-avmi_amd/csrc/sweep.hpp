@@ -111,6 +111,73 @@ __device__ __forceinline__ int sweep_nn2(const double2* sxy, const int32_t* sori
     return bpos;
 }
 
+// The two nearest target points (positions p1, p2; p2 = -1 if the cloud has one
+// point) with their squared distances s1 <= s2, and the squared distance s3 of
+// the third nearest (inf if there is none).  Window of the third distance.
+// Ordering rule as everywhere: (squared distance, original row) ascending.
+struct Top2 {
+    int p1, p2;
+    double s1, s2, s3;
+};
+
+__device__ __forceinline__ Top2 sweep_top2(const double2* sxy, const int32_t* sorig, int m, int dir, double uabs,
+                                           double qx, double qy, int start) {
+    const double uq = proj(dir, qx, qy);
+    Top2 t;
+    t.p1 = 0; t.p2 = -1;
+    t.s1 = t.s2 = t.s3 = __builtin_inf();
+    int r1 = 0x7fffffff, r2 = 0x7fffffff;
+    double thr = __builtin_inf();
+    int lo, hi;
+    if (start >= 0 && start < m) {
+        const double2 c = sxy[start];
+        const double dx = qx - c.x, dy = qy - c.y;
+        double s = 0.0;
+        s += dx * dx;
+        s += dy * dy;
+        t.s1 = s; t.p1 = start; r1 = sorig[start];
+        lo = start - 1; hi = start + 1;
+    } else {
+        hi = sweep_lower_bound(sxy, m, dir, uq);
+        lo = hi - 1;
+    }
+    while (lo >= 0 || hi < m) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const bool right = side == 0;
+            if (right ? hi < m : lo >= 0) {
+                const int i = right ? hi : lo;
+                const double2 c = sxy[i];
+                const double du = right ? proj(dir, c.x, c.y) - uq : uq - proj(dir, c.x, c.y);
+                if (du > thr) { if (right) hi = m; else lo = -1; }      // everything further out is farther than the third
+                else {
+                    if (du >= -thr) {
+                        const double dx = qx - c.x, dy = qy - c.y;
+                        double s = 0.0;
+                        s += dx * dx;
+                        s += dy * dy;
+                        if (s <= t.s2) {                             // enters the top two (or ties with the second)
+                            const int row = sorig[i];
+                            if (s < t.s1 || (s == t.s1 && row < r1)) {
+                                t.s3 = t.s2; t.s2 = t.s1; t.p2 = t.p1; r2 = r1;
+                                t.s1 = s; t.p1 = i; r1 = row;
+                            } else if (s < t.s2 || row < r2) {
+                                t.s3 = t.s2; t.s2 = s; t.p2 = i; r2 = row;
+                            } else t.s3 = s;                         // tie with the second, lost on the row
+                            thr = prune_width(dir, t.s3, uq, uabs);
+                        } else if (s < t.s3) {
+                            t.s3 = s;
+                            thr = prune_width(dir, t.s3, uq, uabs);
+                        }
+                    }
+                    if (right) ++hi; else --lo;
+                }
+            }
+        }
+    }
+    return t;
+}
+
 // 1-NN of (qx, qy) in the sorted cloud.  Returns the sorted position; d2 is the
 // squared distance; ties go to the lowest original row (sorig).  `start` >= 0 is
 // a position to start from (the previous iteration's match: it seeds the bound
