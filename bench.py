@@ -102,15 +102,14 @@ def main():
     M = cnt[batch.pair_tgt_host].astype(np.float64)
     it = local[:, _lib.RES_ITERS]
     alg_bytes = float((it * (28.0 * N + 16.0 * M)).sum())    # 16N+16M read + 12N written per pair-iteration
-    evals = float((it * N * M).sum())
     k_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    roofline = {"kernel": "icp_fused_kernel<2>", "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+    roofline = {"kernel": "icp2_fused_kernel (fused ICP, sorted-sweep search)" if batch.fast else "icp_fused_kernel",
+                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                "valu": {"distance_evals_per_launch": evals, "fp64_ops_per_eval": 6,
-                         "achieved_Tops": round(evals * 6 / (k_ms * 1e-3) / 1e12, 3), "peak_Tops": FP64_VALU_PEAK_TOPS,
-                         "frac": round(evals * 6 / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS, 4)}}
+                "pair_iterations_per_launch": float(it.sum()),
+                "note": "algorithmic bytes = sum over pairs of iterations x (28 N + 16 M), N/M rows after voxel filtering"}
 
     line = {"metric": "icp_iterations_per_sec", "value": round(value, 1), "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -138,6 +137,7 @@ def main():
         it1 = float(one.results.cpu().numpy()[0, _lib.RES_ITERS])
         line["single_pair"] = {"ms_per_icp": round(lat * 1e3, 4), "iterations": it1,
                                "iterations_per_sec": round(it1 / lat, 1)}
+        line["nn_exhaustive"] = bench_nn_exhaustive(torch, batch, _lib)
         if not args.no_raycast:
             line["raycast"] = bench_raycast(torch, synth, args.raycast_scans, not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
@@ -146,6 +146,39 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_nn_exhaustive(torch, batch, _lib):
+    """K1, the LDS-tiled exhaustive NN kernel north_star names, on the same voxel-filtered pairs (one NN pass each)."""
+    import ctypes as C
+    from icpmi.batch import _ptr, _stream
+    L = _lib.lib()
+    B, stride = batch.B, batch.max_src_n
+    idx = torch.empty((B, stride), dtype=torch.int32, device=batch.vox.pts.device)
+    dist = torch.empty((B, stride), dtype=torch.float64, device=batch.vox.pts.device)
+
+    def go():
+        _lib.check(L.icpmi_nn_batch(_ptr(batch.vox.pts), _ptr(batch.vox.off), _ptr(batch.vox.cnt), _ptr(batch.pair_src),
+                                    _ptr(batch.pair_tgt), B, stride, 2, _ptr(idx), _ptr(dist), stride, _stream()), "nn")
+    for _ in range(3):
+        go()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        go()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    cnt = batch.vox.cnt.cpu().numpy()
+    N = cnt[batch.pair_src_host].astype(np.float64)
+    M = cnt[batch.pair_tgt_host].astype(np.float64)
+    byts, evals = float((28.0 * N + 16.0 * M).sum()), float((N * M).sum())
+    gbs, tops = byts / (ms * 1e-3) / 1e9, evals * 6 / (ms * 1e-3) / 1e12
+    return {"kernel": "nn_batch_kernel<2,S>", "pairs": B, "kernel_ms": round(ms, 4),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": byts},
+            "valu": {"distance_evals_per_launch": evals, "fp64_ops_per_eval": 6, "achieved_Tops": round(tops, 3),
+                     "peak_Tops": FP64_VALU_PEAK_TOPS, "frac": round(tops / FP64_VALU_PEAK_TOPS, 4)}}
 
 
 def bench_raycast(torch, synth, n_scans, with_cpu):
@@ -204,14 +237,15 @@ def cpu_baseline(srcs, tgts):
     oracle.icp(srcs[0], tgts[0], **ICP_KW)
     t0 = time.perf_counter()
     iters = n = 0
-    for s, t in zip(srcs, tgts):
-        iters += oracle.icp(s, t, **ICP_KW)[3]["iters"]
-        n += 1
-        if time.perf_counter() - t0 > 15.0:
-            break
+    while time.perf_counter() - t0 < 12.0:                  # a bounded ~12 s sample: the pair list, repeated
+        for s, t in zip(srcs, tgts):
+            iters += oracle.icp(s, t, **ICP_KW)[3]["iters"]
+            n += 1
+            if time.perf_counter() - t0 > 12.0:
+                break
     dt = time.perf_counter() - t0
     return {"value": round(iters / dt, 1), "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{n} of the same scan pairs, {iters} iterations, {dt:.1f} s, oracle/icp_oracle.c (k-d tree NN)",
+            "sample": f"{n} ICP calls on the same scan pairs, {iters} iterations, {dt:.1f} s, oracle/icp_oracle.c (k-d tree NN)",
             "host_cpus": os.cpu_count()}
 
 

@@ -60,11 +60,20 @@ __device__ __forceinline__ void nn_scan_tile(const double* tile, int padded, int
         double cm[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) cm[s] = __builtin_inf();
+        // Two half-chunks: the 8 (DIM doubles) targets of a half are fetched into registers before
+        // any of them is used, so their ds_reads are all in flight together instead of one
+        // read -> wait -> 6*S flops at a time.
 #pragma unroll
-        for (int jj = 0; jj < NN_CHUNK; ++jj) {
-            const double* q = tile + (c0 + jj) * DIM;
+        for (int h = 0; h < NN_CHUNK; h += 8) {
+            double q[8][DIM];
 #pragma unroll
-            for (int s = 0; s < S; ++s) cm[s] = fmin(cm[s], sqdist<DIM>(p[s], q));
+            for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) q[jj][d] = tile[(c0 + h + jj) * DIM + d];
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+                for (int s = 0; s < S; ++s) cm[s] = fmin(cm[s], sqdist<DIM>(p[s], q[jj]));
         }
 #pragma unroll
         for (int s = 0; s < S; ++s)

@@ -41,11 +41,13 @@ struct TopKP {
             }
         }
     }
-    __device__ __forceinline__ void push(double s, int row, int pos) {
+    __device__ __forceinline__ bool push(double s, int row, int pos) {
         if (s < d[KK - 1] || (s == d[KK - 1] && row < j[KK - 1])) {
             d[KK - 1] = s; j[KK - 1] = row; p[KK - 1] = pos;
             bubble<KK - 1>();
+            return true;
         }
+        return false;
     }
     template <int I>
     __device__ __forceinline__ double kth_from(int k, double v) const {
@@ -64,39 +66,37 @@ struct TopKP {
 };
 
 template <int KK>
-__device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* sorig, int M, int dir, int kk,
+__device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* sorig, int M, int s_begin, int s_end, int dir, int kk,
                                              double2* __restrict__ out_sorted, double* __restrict__ out_rows) {
-    for (int s = threadIdx.x; s < M; s += blockDim.x) {
+    const double2 c_lo = sxy[0], c_hi = sxy[M - 1];
+    const double uabs = fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y)));
+    for (int s = s_begin + threadIdx.x; s < s_end; s += blockDim.x) {
         const double2 q = sxy[s];
         const double uq = proj(dir, q.x, q.y);
         TopKP<KK> top;
         top.init();
         top.push(0.0, sorig[s], s);
+        // window half-width from the current kk-th best distance (inf until kk neighbours are known);
+        // refreshed only when the list changes
+        double thr = __builtin_inf();
         int lo = s - 1, hi = s + 1;
         while (lo >= 0 || hi < M) {
-            const double kth = top.kth(kk - 1);
-            if (hi < M) {
-                const double2 c = sxy[hi];
-                if (gap_exceeds(dir, uq, proj(dir, c.x, c.y), kth)) hi = M;
-                else {
-                    const double dx = q.x - c.x, dy = q.y - c.y;
-                    double d2 = 0.0;
-                    d2 += dx * dx;
-                    d2 += dy * dy;
-                    top.push(d2, sorig[hi], hi);
-                    ++hi;
-                }
-            }
-            if (lo >= 0) {
-                const double2 c = sxy[lo];
-                if (gap_exceeds(dir, uq, proj(dir, c.x, c.y), kth)) lo = -1;
-                else {
-                    const double dx = q.x - c.x, dy = q.y - c.y;
-                    double d2 = 0.0;
-                    d2 += dx * dx;
-                    d2 += dy * dy;
-                    top.push(d2, sorig[lo], lo);
-                    --lo;
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const bool right = side == 0;
+                if (right ? hi < M : lo >= 0) {
+                    const int i = right ? hi : lo;
+                    const double2 c = sxy[i];
+                    const double du = right ? proj(dir, c.x, c.y) - uq : uq - proj(dir, c.x, c.y);
+                    if (du > thr) { if (right) hi = M; else lo = -1; }
+                    else {
+                        const double dx = q.x - c.x, dy = q.y - c.y;
+                        double d2 = 0.0;
+                        d2 += dx * dx;
+                        d2 += dy * dy;
+                        if (top.push(d2, sorig[i], i)) thr = prune_width(dir, kk == KK ? top.d[KK - 1] : top.kth(kk - 1), uq, uabs);
+                        if (right) ++hi; else --lo;
+                    }
                 }
             }
         }
@@ -128,11 +128,15 @@ template <int KK>
 __global__ __launch_bounds__(PREP_THREADS) void prep_targets_kernel(
     const double* __restrict__ pts, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
     const int32_t* __restrict__ cloud_ids, int k, double2* __restrict__ g_sxy, double2* __restrict__ g_snrm,
-    int32_t* __restrict__ g_sorig, int32_t* __restrict__ g_dir, double* __restrict__ out_normals, int lds_points) {
+    int32_t* __restrict__ g_sorig, int32_t* __restrict__ g_dir, double* __restrict__ out_normals, int lds_points,
+    int split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ double dsc[8 * PREP_MAXW];
     __shared__ int hist[4 * PREP_BINS];
-    const int c = cloud_ids ? cloud_ids[blockIdx.x] : blockIdx.x;
+    // `split` workgroups share one cloud: each repeats the (cheap) axis choice and sort, then takes its
+    // slice of the normal queries — small batches would otherwise leave a cloud's k-NN sweeps to one CU
+    const int ci = blockIdx.x / split, part = blockIdx.x % split;
+    const int c = cloud_ids ? cloud_ids[ci] : ci;
     const int M = cnt ? cnt[c] : off[c + 1] - off[c];
     if (M <= 0 || M > lds_points) { if (threadIdx.x == 0) g_dir[c] = -1; return; }
     const double* P = pts + (size_t)off[c] * 2;
@@ -201,16 +205,17 @@ __global__ __launch_bounds__(PREP_THREADS) void prep_targets_kernel(
         const int row = (int)rows[i];
         const double2 p = make_double2(P[2 * row], P[2 * row + 1]);
         sxy[i] = p; sorig[i] = row;
-        o_sxy[i] = p; o_sorig[i] = row;
+        if (part == 0) { o_sxy[i] = p; o_sorig[i] = row; }
     }
-    if (threadIdx.x == 0) g_dir[c] = dir;
+    if (threadIdx.x == 0 && part == 0) g_dir[c] = dir;
     __syncthreads();
     if constexpr (KK > 0) {
         const int kc = min(k, M - 1);              // icp.py:61
         const int kk = kc + 1;                     // self included, icp.py:66
         double2* o_snrm = g_snrm + off[c];
         double* o_rows = out_normals ? out_normals + (size_t)off[c] * 2 : nullptr;
-        prep_normals<KK>(sxy, sorig, M, dir, kk, o_snrm, o_rows);
+        const int per = (M + split - 1) / split;
+        prep_normals<KK>(sxy, sorig, M, min(M, part * per), min(M, (part + 1) * per), dir, kk, o_snrm, o_rows);
     }
 }
 
@@ -240,15 +245,22 @@ extern "C" int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, 
     int npad = 64;
     while (npad < max_n) npad <<= 1;
     const size_t lds = (size_t)npad * 20 + (size_t)npad * 12;      // lds_points = npad
+    int split = 512 / n_sel;                 // enough workgroups for every CU when the batch is small
+    split = split < 1 ? 1 : (split > 8 ? 8 : split);
 #define ICPMI_PREP_GO(KKV)                                                                                              \
     do {                                                                                                                \
         if (hipFuncSetAttribute((const void*)prep_targets_kernel<KKV>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
                                 (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                          \
-        prep_targets_kernel<KKV><<<n_sel, PREP_THREADS, lds, (hipStream_t)stream>>>(                                    \
-            pts, off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig, g_dir, out_normals, npad);              \
+        prep_targets_kernel<KKV><<<n_sel * (KKV > 0 ? split : 1), PREP_THREADS, lds, (hipStream_t)stream>>>(           \
+            pts, off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig, g_dir, out_normals, npad,               \
+            KKV > 0 ? split : 1);                                                                                       \
     } while (0)
+    // list capacity = k + 1 exactly for the usual k (5, 10 = reference default, 12 = config.yaml), else the next size up
     if (normal_k < 0) ICPMI_PREP_GO(0);
+    else if (normal_k + 1 <= 6) ICPMI_PREP_GO(6);
     else if (normal_k + 1 <= 8) ICPMI_PREP_GO(8);
+    else if (normal_k + 1 <= 11) ICPMI_PREP_GO(11);
+    else if (normal_k + 1 <= 13) ICPMI_PREP_GO(13);
     else if (normal_k + 1 <= 16) ICPMI_PREP_GO(16);
     else ICPMI_PREP_GO(32);
 #undef ICPMI_PREP_GO

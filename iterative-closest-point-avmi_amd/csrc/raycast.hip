@@ -25,10 +25,15 @@
 namespace icpmi {
 
 constexpr int RC_THREADS = 256;
-constexpr int RC_STEPS = 16;          // Bresenham steps per chunk
-constexpr int RC_SLOTS = 16;          // chunk slots per 64-beam group (grid-stride over longer rays)
+#ifndef ICPMI_RC_STEPS
+#define ICPMI_RC_STEPS 16
+#define ICPMI_RC_SLOTS 16
+#define ICPMI_RC_FIN_BLOCKS 1024
+#endif
+constexpr int RC_STEPS = ICPMI_RC_STEPS;   // Bresenham steps per chunk
+constexpr int RC_SLOTS = ICPMI_RC_SLOTS;   // chunk slots per 64-beam group (grid-stride over longer rays)
 constexpr int RC_COORD_MAX = 1 << 29; // cell coordinates are clamped to +-2^29
-constexpr int RC_FIN_BLOCKS = 1024;
+constexpr int RC_FIN_BLOCKS = ICPMI_RC_FIN_BLOCKS;
 
 struct GridDesc {
     int nx, ny;
@@ -96,11 +101,12 @@ struct Ray {
 // mode bits
 constexpr int RC_DO_HITS = 1, RC_DO_MISS = 2, RC_PACKED = 4;
 
-__global__ __launch_bounds__(RC_THREADS) void ray_count_kernel(
-    GridDesc g, const double* __restrict__ origin, const double* __restrict__ hits, int nb,
-    uint32_t* __restrict__ counts, BBox* bbox, int mode) {
+// K6 body; `block` = index of this workgroup among the counting workgroups of the launch
+__device__ __forceinline__ void ray_count_body(
+    const GridDesc& g, const double* __restrict__ origin, const double* __restrict__ hits, int nb,
+    uint32_t* __restrict__ counts, BBox* bbox, int mode, int block) {
     const int lane = lane_id();
-    const int gw = (blockIdx.x * RC_THREADS + threadIdx.x) >> 6;        // global wave id
+    const int gw = (block * RC_THREADS + threadIdx.x) >> 6;             // global wave id
     const int group = gw / RC_SLOTS, slot = gw % RC_SLOTS;
     const int beam = group * ICPMI_WAVE + lane;
     int ox = 0, oy = 0, hx = 0, hy = 0;
@@ -208,10 +214,26 @@ __device__ __forceinline__ float apply_counts(float v0, uint32_t H, uint32_t M, 
     return v;
 }
 
-// count_kind: 0 = packed (H<<16 | M), 1 = counts are hits, 2 = counts are misses
-__global__ __launch_bounds__(RC_THREADS) void ray_finalize_kernel(
-    GridDesc g, float* __restrict__ log_odds, uint32_t* __restrict__ counts, const BBox* bbox, BBox* other,
-    double l_hit, double l_miss, float lo32, float hi32, int count_kind, int clip, int full_clip) {
+struct FinArgs {
+    float* log_odds;
+    uint32_t* counts;
+    const BBox* bbox;
+    BBox* other;          // bounding-box slot to zero for a later scan (may be null)
+    double l_hit, l_miss;
+    float lo32, hi32;
+    int count_kind;       // 0 = packed (H<<16 | M), 1 = counts are hits, 2 = counts are misses
+    int clip, full_clip;
+};
+
+// K7 body; `block` of `nblocks` finalising workgroups
+__device__ __forceinline__ void ray_finalize_body(const GridDesc& g, const FinArgs& f, int block, int nblocks) {
+    float* __restrict__ log_odds = f.log_odds;
+    uint32_t* __restrict__ counts = f.counts;
+    const BBox* bbox = f.bbox;
+    BBox* other = f.other;
+    const double l_hit = f.l_hit, l_miss = f.l_miss;
+    const float lo32 = f.lo32, hi32 = f.hi32;
+    const int count_kind = f.count_kind, clip = f.clip, full_clip = f.full_clip;
     int x0, y0, x1, y1;
     const BBox bb = *bbox;
     if (full_clip) { x0 = 0; y0 = 0; x1 = g.nx - 1; y1 = g.ny - 1; }
@@ -219,7 +241,7 @@ __global__ __launch_bounds__(RC_THREADS) void ray_finalize_kernel(
         if (bb.inv_x0 == 0) { x0 = 0; y0 = 0; x1 = -1; y1 = -1; }
         else { x0 = g.nx - (int)bb.inv_x0; y0 = g.ny - (int)bb.inv_y0; x1 = (int)bb.x1p - 1; y1 = (int)bb.y1p - 1; }
     }
-    for (int y = y0 + blockIdx.x; y <= y1; y += gridDim.x)
+    for (int y = y0 + block; y <= y1; y += nblocks)
         for (int x = x0 + threadIdx.x; x <= x1; x += RC_THREADS) {
             const size_t c = (size_t)y * g.nx + x;
             const uint32_t cn = counts[c];
@@ -235,7 +257,27 @@ __global__ __launch_bounds__(RC_THREADS) void ray_finalize_kernel(
                 log_odds[c] = v;
             }
         }
-    if (other && blockIdx.x == 0 && threadIdx.x == 0) { other->inv_x0 = 0; other->inv_y0 = 0; other->x1p = 0; other->y1p = 0; }
+    if (other && block == 0 && threadIdx.x == 0) { other->inv_x0 = 0; other->inv_y0 = 0; other->x1p = 0; other->y1p = 0; }
+}
+
+__global__ __launch_bounds__(RC_THREADS) void ray_count_kernel(
+    GridDesc g, const double* __restrict__ origin, const double* __restrict__ hits, int nb,
+    uint32_t* __restrict__ counts, BBox* bbox, int mode) {
+    ray_count_body(g, origin, hits, nb, counts, bbox, mode, blockIdx.x);
+}
+
+__global__ __launch_bounds__(RC_THREADS) void ray_finalize_kernel(GridDesc g, FinArgs f) {
+    ray_finalize_body(g, f, blockIdx.x, gridDim.x);
+}
+
+// One launch of a replay: the first n_count workgroups count scan k into one counter grid while
+// the others finalise scan k-1 from the other counter grid — the two touch disjoint memory, so a
+// replay of S scans is S+1 dependent launches instead of 2S.
+__global__ __launch_bounds__(RC_THREADS) void ray_step_kernel(
+    GridDesc g, const double* __restrict__ origin, const double* __restrict__ hits, int nb,
+    uint32_t* __restrict__ counts, BBox* bbox, int mode, int n_count, FinArgs f) {
+    if ((int)blockIdx.x < n_count) ray_count_body(g, origin, hits, nb, counts, bbox, mode, blockIdx.x);
+    else ray_finalize_body(g, f, blockIdx.x - n_count, gridDim.x - n_count);
 }
 
 __global__ void world_to_grid_kernel(const double* __restrict__ w, long long n, double mn, double res, long long* __restrict__ out) {
@@ -264,9 +306,10 @@ __global__ void bresenham_cells_kernel(const int32_t* __restrict__ segs, const l
 
 }  // namespace icpmi
 
+// two counter grids (scan parity) + three bounding-box slots (scan index mod 3)
 extern "C" size_t icpmi_grid_workspace_bytes(int32_t ny, int32_t nx) {
     if (ny <= 0 || nx <= 0) return 0;
-    return (size_t)ny * (size_t)nx * sizeof(uint32_t) + 256;
+    return 2 * (size_t)ny * (size_t)nx * sizeof(uint32_t) + 256;
 }
 
 extern "C" int icpmi_world_to_grid(const double* w, int64_t n, double min_w, double resolution, int64_t* out, void* stream) {
@@ -294,10 +337,15 @@ extern "C" int icpmi_grid_update_scans(float* log_odds, void* counts_ws, int32_t
     if (!log_odds || !counts_ws || !origins || !hit_off_host || ny <= 0 || nx <= 0 || n_scans < 0) return ICPMI_ERR_ARG;
     if (ny > RC_COORD_MAX || nx > RC_COORD_MAX || !(resolution > 0.0)) return ICPMI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    uint32_t* counts = (uint32_t*)counts_ws;
-    BBox* slots = (BBox*)((unsigned char*)counts_ws + (size_t)ny * (size_t)nx * sizeof(uint32_t));
+    const size_t cells = (size_t)ny * (size_t)nx;
+    uint32_t* grid2[2] = {(uint32_t*)counts_ws, (uint32_t*)counts_ws + cells};
+    BBox* slots = (BBox*)((unsigned char*)counts_ws + 2 * cells * sizeof(uint32_t));
     GridDesc g{nx, ny, min_x, min_y, resolution};
-    const float lo32 = (float)lo, hi32 = (float)hi;
+    FinArgs fin{};
+    fin.log_odds = log_odds; fin.l_hit = l_hit; fin.l_miss = l_miss; fin.lo32 = (float)lo; fin.hi32 = (float)hi;
+    bool pending = false;            // a counted scan whose finalisation rides on the next launch
+    int64_t q = scan_seq;            // index of the next non-empty scan (counter grid q&1, box slot q%3)
+    int clip_all = full_clip;
     for (int s = 0; s < n_scans; ++s) {
         const int nb = hit_off_host[s + 1] - hit_off_host[s];
         if (nb < 0) return ICPMI_ERR_ARG;
@@ -305,22 +353,36 @@ extern "C" int icpmi_grid_update_scans(float* log_odds, void* counts_ws, int32_t
         if (!hits) return ICPMI_ERR_ARG;
         const double* h = hits + 2 * (size_t)hit_off_host[s];
         const double* o = origins + 2 * (size_t)s;
-        BBox* cur = slots + ((scan_seq + s) & 1);
-        BBox* oth = slots + ((scan_seq + s + 1) & 1);
         const int groups = (nb + ICPMI_WAVE - 1) / ICPMI_WAVE;
         const long waves = (long)groups * RC_SLOTS;
-        const unsigned blocks = (unsigned)((waves * ICPMI_WAVE + RC_THREADS - 1) / RC_THREADS);
+        const int blocks = (int)((waves * ICPMI_WAVE + RC_THREADS - 1) / RC_THREADS);
+        uint32_t* counts = grid2[q & 1];
+        BBox* cur = slots + (q % 3);
         if (nb <= 65535) {
-            ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, RC_DO_HITS | RC_DO_MISS | RC_PACKED);
-            ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, log_odds, counts, cur, oth, l_hit, l_miss, lo32, hi32, 0, 1, full_clip);
+            const int mode = RC_DO_HITS | RC_DO_MISS | RC_PACKED;
+            if (pending) ray_step_kernel<<<blocks + RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, mode, blocks, fin);
+            else ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, mode);
+            // this scan's finalisation: reads its own grid and slot, frees the slot two scans ahead
+            fin.counts = counts; fin.bbox = cur; fin.other = slots + ((q + 2) % 3);
+            fin.count_kind = 0; fin.clip = 1; fin.full_clip = clip_all;
+            pending = true;
         } else {
-            // more beams than a 16-bit counter holds: hits and misses in two rounds
+            // more beams than a 16-bit counter holds: hits and misses in two rounds, no pipelining
+            if (pending) { ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, fin); pending = false; }
+            FinArgs w = fin;
+            w.counts = counts; w.bbox = cur; w.full_clip = 0;
             ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, RC_DO_HITS);
-            ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, log_odds, counts, cur, nullptr, l_hit, l_miss, lo32, hi32, 1, 0, 0);
+            w.other = nullptr; w.count_kind = 1; w.clip = 0;
+            ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, w);
             ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, RC_DO_MISS);
-            ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, log_odds, counts, cur, oth, l_hit, l_miss, lo32, hi32, 2, 1, full_clip);
+            w.other = slots + ((q + 2) % 3); w.count_kind = 2; w.clip = 1; w.full_clip = clip_all;
+            ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, w);
         }
+        clip_all = 0;                                           // every cell is inside [lo, hi] after one clipped scan
+        ++q;
         ICPMI_LAUNCH_CHECK();
     }
+    if (pending) ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, fin);
+    ICPMI_LAUNCH_CHECK();
     return ICPMI_OK;
 }

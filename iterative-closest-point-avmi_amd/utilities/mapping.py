@@ -38,7 +38,7 @@ class OccupancyGrid2D:
         self._grid = torch.zeros((self.ny, self.nx), dtype=torch.float32, device=self._dev)
         self._ws = torch.zeros(_lib.lib().icpmi_grid_workspace_bytes(self.ny, self.nx), dtype=torch.uint8,
                                device=self._dev)
-        self._seq = 0                      # scans applied so far (bounding-box slot parity)
+        self._seq = 0                      # non-empty scans applied so far (selects counter grid / box slot)
         self._host = None                  # cached host copy of the grid
         self._full_clip = not (self.log_odds_min <= 0.0 <= self.log_odds_max)
         self.cell_updates = 0              # not tracked on the device; see update_scans()
@@ -140,7 +140,7 @@ class OccupancyGrid2D:
                                              self.log_odds_min, self.log_odds_max, self._seq,
                                              1 if self._full_clip else 0, _b._stream()), "update_scan")
         applied = int(np.count_nonzero(np.diff(off)))
-        self._seq += S
+        self._seq += applied
         if applied:
             self._full_clip = False        # every cell is inside [min, max] after a clipped scan
         self._host = None
