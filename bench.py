@@ -111,6 +111,17 @@ def main():
                 "pair_iterations_per_launch": float(it.sum()),
                 "note": "algorithmic bytes = sum over pairs of iterations x (28 N + 16 M), N/M rows after voxel filtering"}
 
+    # HBM bytes per launch from the PMC counters cannot be collected from inside this process: they come from the
+    # committed rocprofv3 --pmc passes of this very command (profiles/r01_pmc_traffic.json), same workload and grid.
+    try:
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        key = [k for k in pmc if "icp2_fused_kernel" in k and f"[{B} workgroups]" in k]
+        if batch.fast and key:
+            roofline["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+    except (OSError, KeyError, ValueError):
+        pass
+
     line = {"metric": "icp_iterations_per_sec", "value": round(value, 1), "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
