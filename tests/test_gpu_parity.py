@@ -404,3 +404,50 @@ def test_icp_on_degenerate_layouts_runs(uicp):
                 R, t, err, info = batch.icp_batch([src], [tgt], 1e-12, 30, 1e-4, method=method, normal_k=6,
                                                   force_exhaustive=force)
                 assert info["status"][0] in (1, 2) and 1 <= info["iters"][0] <= 30
+
+
+# ── full-size properties (BASELINE config 5 shape: 512 pairs) ───────────────
+def test_batch512_properties(uicp):
+    """Size-independent checks on the bench-sized batch: bitwise reproducible, independent of the order and
+    of the company a pair keeps in the batch, equal to the oracle on a sample, known rigid motion recovered."""
+    from icpmi import batch, synth
+    kw = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+    srcs, tgts = synth.loop_closure_batch(512, seed0=1000)
+    b = batch.IcpBatch(srcs + tgts, np.arange(512), np.arange(512, 1024), **kw)
+    r1 = b.run().cpu().numpy().copy()
+    r2 = b.run().cpu().numpy().copy()
+    assert np.array_equal(r1, r2)                                    # fixed reduction trees, integer atomics only
+    perm = np.random.default_rng(0).permutation(512)
+    bp = batch.IcpBatch(srcs + tgts, perm, 512 + perm, **kw)
+    assert np.array_equal(bp.run().cpu().numpy(), r1[perm])          # a pair's result does not depend on its slot
+    sub = batch.IcpBatch([srcs[7], tgts[7], srcs[300], tgts[300]], [0, 2], [1, 3], **kw)
+    assert np.array_equal(sub.run().cpu().numpy()[:2], r1[[7, 300]])  # ... nor on the batch it is in
+    st = r1[:, 15].astype(int)
+    assert set(np.unique(st)) <= {1, 2} and (r1[:, 14] >= 2).all() and (r1[:, 14] <= 150).all()
+    assert np.isfinite(r1[:, :13]).all()
+    for i in (0, 2, 5, 161, 511):                                     # includes pairs that run to max_iterations
+        Ro, to, eo, io = oracle.icp(srcs[i], tgts[i], **kw)
+        assert rot_err(r1[i, :4].reshape(2, 2), r1[i, 9:11], Ro, to) < FRO_TOL, i
+        assert int(r1[i, 14]) == io["iters"] and st[i] == io["status"], i
+    # rotations are proper and the totals compose to what the moved cloud shows: det R = 1, R^T R = I
+    R = r1[:, :4].reshape(-1, 2, 2)
+    assert np.abs(np.linalg.det(R) - 1).max() < 1e-12
+    assert np.abs(np.einsum("bij,bik->bjk", R, R) - np.eye(2)).max() < 1e-12
+
+
+def test_known_motion_recovered(uicp):
+    """Target = source moved by a known rigid motion (same points): every method must return that motion."""
+    from icpmi import batch, synth
+    rng = np.random.default_rng(4)
+    srcs, tgts, truth = [], [], []
+    for i in range(16):
+        s = synth.scan((0.2 * i - 1.0, 0.1 * i, 0.05 * i), 50 + i)
+        th = np.deg2rad(rng.uniform(-4, 4))
+        R = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        t = rng.uniform(-0.15, 0.15, size=2)
+        srcs.append(s); tgts.append(s @ R.T + t); truth.append((R, t))
+    for method in ("point_to_point", "point_to_line"):
+        # voxel 1e-7: every point is its own voxel, so the filtered clouds are exact images of each other
+        R, t, err, info = batch.icp_batch(srcs, tgts, 1e-16, 300, 1e-7, method=method, normal_k=10)
+        worst = max(rot_err(R[i], t[i], Rt, tt) for i, (Rt, tt) in enumerate(truth))
+        assert worst < (1e-5 if method == "point_to_point" else 1e-8), (method, worst)
