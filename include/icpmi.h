@@ -123,11 +123,12 @@ int icpmi_p2l_solve_2d(const double* src, int32_t n_src, const double* tgt, cons
  * any source cloud, max_tgt_n those of any target cloud, total_rows = off[C].
  *
  * prepared (optional): buffer filled by icpmi_prepare_targets for the target
- * clouds of this batch.  With it, 2-D pairs whose clouds have at most 4096 rows
- * run on the fast kernel (exact sweep search on the axis-sorted target copy,
- * pair state in LDS/registers; `normals` and `workspace` are then not read).
- * Without it, or for 3-D / larger clouds, the exhaustive LDS-tiled kernel runs
- * and needs `workspace` (and `normals` for point_to_line).  Results agree. */
+ * clouds of this batch.  With it, 2-D pairs whose source has at most 4096 rows
+ * run on the fast kernel (exact sweep search on the axis-sorted target copy —
+ * staged in LDS up to 4096 target rows, read in place through L2 above; pair
+ * state in registers; `normals` and `workspace` are then not read).  Without
+ * it, or for 3-D / larger sources, the exhaustive LDS-tiled kernel runs and
+ * needs `workspace` (and `normals` for point_to_line).  Results agree. */
 size_t icpmi_icp_workspace_bytes(int32_t n_pairs, int32_t max_src_n, int32_t dim);
 int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
                     const double* normals, const void* prepared,
@@ -143,12 +144,19 @@ int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const int32_t* cn
  * (icpmi_prepared_bytes(total_rows, n_clouds) bytes).  normal_k >= 0 also
  * computes estimate_normals_2d (icp.py:51-76) with k = normal_k: stored in
  * sorted order inside `prepared`, and in row order in out_normals if given.
- * normal_k < 0 skips normals (point_to_point). */
-size_t icpmi_prepared_bytes(int32_t total_rows, int32_t n_clouds);
-int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
-                          const int32_t* cloud_ids, int32_t n_sel, int32_t n_clouds,
-                          int32_t total_rows, int32_t max_n, int32_t normal_k,
-                          double* out_normals, void* prepared, size_t prepared_bytes, void* stream);
+ * normal_k < 0 skips normals (point_to_point).
+ *
+ * Clouds above 4096 rows (a rolling submap) are prepared through global memory
+ * (rocPRIM sort) and later searched in place through L2; for them the launcher
+ * needs the sizes on the host: off_host mirrors off_dev and cloud_ids_host
+ * mirrors cloud_ids (both may be NULL when max_n <= 4096).  max_n = rows of the
+ * largest selected cloud; it also sizes the sort scratch inside `prepared`. */
+size_t icpmi_prepared_bytes(int32_t total_rows, int32_t n_clouds, int32_t max_n);
+int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, const int32_t* off_host,
+                          const int32_t* cnt_dev, const int32_t* cloud_ids, const int32_t* cloud_ids_host,
+                          int32_t n_sel, int32_t n_clouds, int32_t total_rows, int32_t max_n,
+                          int32_t normal_k, double* out_normals, void* prepared, size_t prepared_bytes,
+                          void* stream);
 
 /* Nearest neighbour on prepared targets (same contract as icpmi_nn_batch, same
  * answers bit for bit, icp.py:179): binary search + outward sweep on the sorted

@@ -331,7 +331,7 @@ extern "C" int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const 
     if (n_pairs == 0) return ICPMI_OK;
     hipStream_t st = (hipStream_t)stream;
     // fast path: prepared (axis-sorted) targets, everything on chip
-    if (prepared && p->dim == 2 && max_src_n <= 4096 && max_tgt_n <= 4096)
+    if (prepared && p->dim == 2 && max_src_n <= 4096)
         return launch_icp2(pts, off_dev, cnt_dev, pair_src, pair_tgt, n_pairs, max_src_n, max_tgt_n, total_rows, p, init,
                            results, prepared, st);
     if (p->method == ICPMI_POINT_TO_LINE && p->dim == 2 && !normals) return ICPMI_ERR_ARG;

@@ -88,7 +88,8 @@ constexpr int partial_doubles() { return NV * 64; }
 constexpr int CTRL_R = 0, CTRL_T = 4, CTRL_STOP = 6, CTRL_MP = 8, CTRL_MQ = 10, CTRL_DOUBLES = 12;
 
 // THREADS x ICP2_SMAX = most source rows a pair may have on this instantiation
-template <int THREADS, int ICP2_SMAX>
+// TGT_LDS: the prepared target is staged in LDS (<= 4096 points); otherwise it is read in place, through L2
+template <int THREADS, int ICP2_SMAX, bool TGT_LDS>
 __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   // 4 waves/SIMD: 2 x 512 or 1 x 1024 per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ double redA[partial_doubles<11>()];     // normal equations (10) / centroid sums (5) + carried squared error
@@ -108,9 +109,13 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
     double* res = a.results + (size_t)b * ICPMI_RES_DOUBLES;
     const int dir = a.g_dir[tc];
 
-    double2* sxy = reinterpret_cast<double2*>(dyn);
-    double2* snrm = reinterpret_cast<double2*>(dyn + (size_t)a.lds_points * 16);
-    int32_t* sorig = reinterpret_cast<int32_t*>(dyn + (size_t)a.lds_points * 32);
+    // two instantiations, each sees ONE address space behind these pointers
+    double2* lds_xy = reinterpret_cast<double2*>(dyn);
+    double2* lds_nrm = reinterpret_cast<double2*>(dyn + (size_t)a.lds_points * 16);
+    int32_t* lds_orig = reinterpret_cast<int32_t*>(dyn + (size_t)a.lds_points * 32);
+    const double2* sxy = TGT_LDS ? lds_xy : a.g_sxy + a.off[tc];
+    const double2* snrm = TGT_LDS ? lds_nrm : a.g_snrm + a.off[tc];
+    const int32_t* sorig = TGT_LDS ? lds_orig : a.g_sorig + a.off[tc];
 
     double rt[4] = {1.0, 0.0, 0.0, 1.0}, tt[2] = {0.0, 0.0};
     if (a.has_init) {                                       // icp.py:153-156
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
     double err = __builtin_inf(), prev = __builtin_inf(), delta = __builtin_inf();
     int iters = 0, status = ICPMI_ST_MAXITER;
 
-    if (N <= 0 || M <= 0 || dir < 0 || M > a.lds_points || N > THREADS * ICP2_SMAX) {
+    if (N <= 0 || M <= 0 || dir < 0 || (TGT_LDS && M > a.lds_points) || N > THREADS * ICP2_SMAX) {
         status = ICPMI_ST_EMPTY;                            // the launcher only sends pairs that fit
     } else {
         const bool use_p2l = a.method == ICPMI_POINT_TO_LINE;
@@ -130,11 +135,12 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
         const double2* gx = a.g_sxy + a.off[tc];
         const double2* gn = a.g_snrm + a.off[tc];
         const int32_t* go = a.g_sorig + a.off[tc];
-        for (int i = tid; i < M; i += THREADS) {
-            sxy[i] = gx[i];
-            sorig[i] = go[i];
-            if (use_p2l) snrm[i] = gn[i];
-        }
+        if constexpr (TGT_LDS)
+            for (int i = tid; i < M; i += THREADS) {
+                lds_xy[i] = gx[i];
+                lds_orig[i] = go[i];
+                if (use_p2l) lds_nrm[i] = gn[i];
+            }
         // moving source rows in registers: row n = s*THREADS + tid
         double px[ICP2_SMAX], py[ICP2_SMAX], d2[ICP2_SMAX];
         int pos[ICP2_SMAX];
@@ -431,21 +437,25 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     a.lds_points = cap;
     a.error_threshold = p->error_threshold; a.max_corr_dist = p->max_corr_dist;
     a.max_iterations = p->max_iterations; a.method = p->method; a.has_init = p->has_init;
-    const size_t lds = (size_t)cap * 36;
+    const bool in_lds = max_tgt_n <= 4096;
+    const size_t lds = in_lds ? (size_t)cap * 36 : 0;
     // Workgroup shape by source size (rows per thread bounded by the instantiation).  ICPMI_ICP2_THREADS
     // (512 / 1024) overrides the thread count for experiments.
     const char* env = getenv("ICPMI_ICP2_THREADS");
     const int want = env ? atoi(env) : 0;
 #define ICPMI_ICP2_GO(T, SM)                                                                                                     \
+    do { if (in_lds) ICPMI_ICP2_GO2(T, SM, true); else ICPMI_ICP2_GO2(T, SM, false); } while (0)
+#define ICPMI_ICP2_GO2(T, SM, L)                                                                                                 \
     do {                                                                                                                         \
-        if (hipFuncSetAttribute((const void*)icp2_fused_kernel<T, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
+        if (hipFuncSetAttribute((const void*)icp2_fused_kernel<T, SM, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
             hipSuccess) return ICPMI_ERR_HIP;                                                                                    \
-        icp2_fused_kernel<T, SM><<<n_pairs, T, lds, st>>>(a);                                                                    \
+        icp2_fused_kernel<T, SM, L><<<n_pairs, T, lds, st>>>(a);                                                                    \
     } while (0)
     if (want == 512 && max_src_n <= 2048) { if (max_src_n <= 1024) ICPMI_ICP2_GO(512, 2); else ICPMI_ICP2_GO(512, 4); }
     else if (want == 1024 || max_src_n > 1024) { if (max_src_n <= 2048) ICPMI_ICP2_GO(1024, 2); else ICPMI_ICP2_GO(1024, 4); }
     else ICPMI_ICP2_GO(512, 2);
 #undef ICPMI_ICP2_GO
+#undef ICPMI_ICP2_GO2
     ICPMI_LAUNCH_CHECK();
     return ICPMI_OK;
 }

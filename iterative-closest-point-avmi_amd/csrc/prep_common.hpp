@@ -1,0 +1,171 @@
+// prep_common.hpp — pieces shared by the LDS (prep.hip) and global-memory (prep_big.hip) target preparation.
+#pragma once
+#include "linalg.hpp"
+#include "sort.hpp"
+#include "sweep.hpp"
+
+namespace icpmi {
+
+constexpr int PREP_BINS = 64;
+
+// Search axis of a cloud: ranges of the four projections x, y, x+y, x-y, a 64-bin histogram per axis, and
+// the axis with the smallest expected search window (sum of squared bin counts / bin width; the diagonals
+// pay sqrt(2) because their projection gap bounds the distance only up to that factor).  All threads of the
+// workgroup call it and get the same answer.  dsc: 8 * THREADS/64 doubles, hist: 4 * PREP_BINS ints of LDS.
+template <int THREADS>
+__device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, double* dsc, int* hist) {
+    constexpr int MAXW = THREADS / ICPMI_WAVE;
+    double mn[4], mx[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { mn[d] = __builtin_inf(); mx[d] = -__builtin_inf(); }
+    for (int i = threadIdx.x; i < M; i += THREADS) {
+        const double x = P[2 * i], y = P[2 * i + 1];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { const double u = proj(d, x, y); mn[d] = fmin(mn[d], u); mx[d] = fmax(mx[d], u); }
+    }
+    const int w = wave_id(), l = lane_id();
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    if (l == 0)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) { dsc[d * MAXW + w] = mn[d]; dsc[(4 + d) * MAXW + w] = mx[d]; }
+    for (int i = threadIdx.x; i < 4 * PREP_BINS; i += THREADS) hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        double a = __builtin_inf(), b = -__builtin_inf();
+        for (int q = 0; q < MAXW; ++q) { a = fmin(a, dsc[d * MAXW + q]); b = fmax(b, dsc[(4 + d) * MAXW + q]); }
+        mn[d] = a; mx[d] = b;
+    }
+    for (int i = threadIdx.x; i < M; i += THREADS) {
+        const double x = P[2 * i], y = P[2 * i + 1];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const double r = mx[d] - mn[d];
+            int b = r > 0.0 ? (int)((proj(d, x, y) - mn[d]) / r * PREP_BINS) : 0;
+            b = b < 0 ? 0 : (b >= PREP_BINS ? PREP_BINS - 1 : b);
+            atomicAdd(&hist[d * PREP_BINS + b], 1);
+        }
+    }
+    __syncthreads();
+    int dir = 0;
+    double bestc = __builtin_inf();
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        double s = 0.0;
+        for (int b = 0; b < PREP_BINS; ++b) { const double cn = (double)hist[d * PREP_BINS + b]; s += cn * cn; }
+        const double r = mx[d] - mn[d];
+        const double cost = r > 0.0 ? (d < 2 ? 1.0 : 1.4142135623730951) * s / r : __builtin_inf();
+        if (cost < bestc) { bestc = cost; dir = d; }       // integer histogram: identical in every thread
+    }
+    return dir;
+}
+
+// k best (d2, row, sorted position), ascending by (d2, row).  Every index is a
+// compile-time constant (template recursion), so the lists stay in registers.
+template <int KK>
+struct TopKP {
+    double d[KK];
+    int j[KK];
+    int p[KK];
+    template <int I>
+    __device__ __forceinline__ void init_from() {
+        if constexpr (I < KK) { d[I] = __builtin_inf(); j[I] = 0x7fffffff; p[I] = 0; init_from<I + 1>(); }
+    }
+    __device__ __forceinline__ void init() { init_from<0>(); }
+    template <int I>
+    __device__ __forceinline__ void bubble() {
+        if constexpr (I > 0) {
+            // stop as soon as the new entry is in place: candidates arrive roughly by
+            // increasing distance, so most insertions move one or two slots
+            if (d[I] < d[I - 1] || (d[I] == d[I - 1] && j[I] < j[I - 1])) {
+                const double td = d[I - 1]; const int tj = j[I - 1], tp = p[I - 1];
+                d[I - 1] = d[I]; j[I - 1] = j[I]; p[I - 1] = p[I];
+                d[I] = td; j[I] = tj; p[I] = tp;
+                bubble<I - 1>();
+            }
+        }
+    }
+    __device__ __forceinline__ bool push(double s, int row, int pos) {
+        if (s < d[KK - 1] || (s == d[KK - 1] && row < j[KK - 1])) {
+            d[KK - 1] = s; j[KK - 1] = row; p[KK - 1] = pos;
+            bubble<KK - 1>();
+            return true;
+        }
+        return false;
+    }
+    template <int I>
+    __device__ __forceinline__ double kth_from(int k, double v) const {
+        if constexpr (I < KK) return kth_from<I + 1>(k, I == k ? d[I] : v);
+        else return v;
+    }
+    __device__ __forceinline__ double kth(int k) const { return kth_from<1>(k, d[0]); }
+    // sum of f(sxy[p[i]]) over i < kk, in list order
+    template <int I, typename F>
+    __device__ __forceinline__ void for_first(int kk, F&& f) const {
+        if constexpr (I < KK) {
+            if (I < kk) f(p[I]);
+            for_first<I + 1>(kk, f);
+        }
+    }
+};
+
+template <int KK>
+__device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* sorig, int M, int s_begin, int s_end, int dir, int kk,
+                                             double2* __restrict__ out_sorted, double* __restrict__ out_rows) {
+    const double2 c_lo = sxy[0], c_hi = sxy[M - 1];
+    const double uabs = fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y)));
+    for (int s = s_begin + threadIdx.x; s < s_end; s += blockDim.x) {
+        const double2 q = sxy[s];
+        const double uq = proj(dir, q.x, q.y);
+        TopKP<KK> top;
+        top.init();
+        top.push(0.0, sorig[s], s);
+        // window half-width from the current kk-th best distance (inf until kk neighbours are known);
+        // refreshed only when the list changes
+        double thr = __builtin_inf();
+        int lo = s - 1, hi = s + 1;
+        while (lo >= 0 || hi < M) {
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const bool right = side == 0;
+                if (right ? hi < M : lo >= 0) {
+                    const int i = right ? hi : lo;
+                    const double2 c = sxy[i];
+                    const double du = right ? proj(dir, c.x, c.y) - uq : uq - proj(dir, c.x, c.y);
+                    if (du > thr) { if (right) hi = M; else lo = -1; }
+                    else {
+                        const double dx = q.x - c.x, dy = q.y - c.y;
+                        double d2 = 0.0;
+                        d2 += dx * dx;
+                        d2 += dy * dy;
+                        if (top.push(d2, sorig[i], i)) thr = prune_width(dir, kk == KK ? top.d[KK - 1] : top.kth(kk - 1), uq, uabs);
+                        if (right) ++hi; else --lo;
+                    }
+                }
+            }
+        }
+        // np.cov over the kk neighbours, summed in ascending (distance, row) order
+        double mx = 0.0, my = 0.0;
+        top.template for_first<0>(kk, [&](int pos) { const double2 c = sxy[pos]; mx += c.x; my += c.y; });
+        mx /= (double)kk; my /= (double)kk;
+        double sxx = 0.0, sxy_ = 0.0, syy = 0.0;
+        top.template for_first<0>(kk, [&](int pos) {
+            const double2 c = sxy[pos];
+            const double dx = c.x - mx, dy = c.y - my;
+            sxx += dx * dx; sxy_ += dx * dy; syy += dy * dy;
+        });
+        double vx = 1.0, vy = 0.0;
+        if (kk > 1) {
+            const double den = (double)(kk - 1);                 // np.cov ddof = 1
+            smallest_evec_2x2(sxx / den, sxy_ / den, syy / den, vx, vy);
+        }
+        double nn = sqrt(vx * vx + vy * vy);
+        nn = nn < 1e-10 ? 1e-10 : nn;                            // icp.py:74-75
+        const double2 n2 = make_double2(vx / nn, vy / nn);
+        out_sorted[s] = n2;
+        if (out_rows) { const int row = sorig[s]; out_rows[2 * row] = n2.x; out_rows[2 * row + 1] = n2.y; }
+    }
+}
+
+}  // namespace icpmi

@@ -124,12 +124,12 @@ def normals_set(cs, k, cloud_ids=None, out=None, workspace=None):
         ids_t = torch.from_numpy(ids).to(cs.pts.device)
     if max_n <= PREP_MAX_POINTS:
         # sweep search on the axis-sorted copy (prep.hip); the sorted copy is a by-product
-        need = L.icpmi_prepared_bytes(cs.total_rows, cs.n_clouds)
+        need = L.icpmi_prepared_bytes(cs.total_rows, cs.n_clouds, max_n)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, dtype=torch.uint8, device=cs.pts.device)
-        check(L.icpmi_prepare_targets(_ptr(cs.pts), _ptr(cs.off), _ptr(cs.cnt), _ptr(ids_t), n_sel, cs.n_clouds,
-                                      cs.total_rows, max_n, int(k), _ptr(out), _ptr(workspace), workspace.numel(),
-                                      _stream()), "estimate_normals_2d")
+        check(L.icpmi_prepare_targets(_ptr(cs.pts), _ptr(cs.off), None, _ptr(cs.cnt), _ptr(ids_t), None, n_sel,
+                                      cs.n_clouds, cs.total_rows, max_n, int(k), _ptr(out), _ptr(workspace),
+                                      workspace.numel(), _stream()), "estimate_normals_2d")
         return out
     need = L.icpmi_normals_workspace_bytes(cs.total_rows, max_n)
     if workspace is None or workspace.numel() < need:
@@ -170,11 +170,11 @@ def nn_set_sweep(cs, pair_src, pair_tgt, return_second=False):
     if max_tgt > PREP_MAX_POINTS:
         raise ValueError(f"target clouds above {PREP_MAX_POINTS} rows need the exhaustive search (nn_set)")
     stride = max(int(sizes[pair_src].max()) if B else 0, 1)
-    prepared = torch.empty(L.icpmi_prepared_bytes(cs.total_rows, cs.n_clouds), dtype=torch.uint8, device=dev)
+    prepared = torch.empty(L.icpmi_prepared_bytes(cs.total_rows, cs.n_clouds, max_tgt), dtype=torch.uint8, device=dev)
     ids = torch.from_numpy(tgt_ids.astype(np.int32)).to(dev)
-    check(L.icpmi_prepare_targets(_ptr(cs.pts), _ptr(cs.off), _ptr(cs.cnt), _ptr(ids), len(tgt_ids), cs.n_clouds,
-                                  cs.total_rows, max_tgt, -1, None, _ptr(prepared), prepared.numel(), _stream()),
-          "prepare_targets")
+    check(L.icpmi_prepare_targets(_ptr(cs.pts), _ptr(cs.off), None, _ptr(cs.cnt), _ptr(ids), None, len(tgt_ids),
+                                  cs.n_clouds, cs.total_rows, max_tgt, -1, None, _ptr(prepared), prepared.numel(),
+                                  _stream()), "prepare_targets")
     ps, pt = torch.from_numpy(pair_src).to(dev), torch.from_numpy(pair_tgt).to(dev)
     idx = torch.empty((max(B, 1), stride), dtype=torch.int32, device=dev)
     dist = torch.empty((max(B, 1), stride), dtype=torch.float64, device=dev)
@@ -237,13 +237,14 @@ class IcpBatch:
         self.tgt_ids_dev = torch.from_numpy(self.tgt_ids.astype(np.int32)).to(dev)
         self.max_tgt_n = int(sizes[self.tgt_ids].max()) if len(self.tgt_ids) else 0
         # fast path: 2-D, every cloud small enough for the on-chip kernels
-        self.fast = (self.dim == 2 and self.max_src_n <= PREP_MAX_POINTS and self.max_tgt_n <= PREP_MAX_POINTS
-                     and not force_exhaustive)
+        # (targets above PREP_MAX_POINTS rows — a rolling submap — are sorted through global memory and searched via L2)
+        self.fast = self.dim == 2 and self.max_src_n <= PREP_MAX_POINTS and not force_exhaustive
         self.prepared = None
         self.icp_ws = None
         if self.fast:
-            self.prepared = torch.empty(L.icpmi_prepared_bytes(self.raw.total_rows, self.raw.n_clouds),
+            self.prepared = torch.empty(L.icpmi_prepared_bytes(self.raw.total_rows, self.raw.n_clouds, self.max_tgt_n),
                                         dtype=torch.uint8, device=dev)
+            self.tgt_ids_host = np.ascontiguousarray(self.tgt_ids, dtype=np.int32)
         else:
             if use_p2l:
                 self.normals = torch.zeros((max(self.raw.total_rows, 1), 2), dtype=torch.float64, device=dev)
@@ -261,10 +262,12 @@ class IcpBatch:
         st = _stream()
         voxel_downsample_set(self.raw, self.voxel_size, out=self.vox, workspace=self.vox_ws)
         if self.fast:
-            check(L.icpmi_prepare_targets(_ptr(self.vox.pts), _ptr(self.vox.off), _ptr(self.vox.cnt),
-                                          _ptr(self.tgt_ids_dev), len(self.tgt_ids), self.raw.n_clouds,
-                                          self.raw.total_rows, self.max_tgt_n, self.normal_k if self.use_p2l else -1,
-                                          None, _ptr(self.prepared), self.prepared.numel(), st), "prepare_targets")
+            check(L.icpmi_prepare_targets(_ptr(self.vox.pts), _ptr(self.vox.off),
+                                          self.raw.off_host.ctypes.data_as(C.c_void_p), _ptr(self.vox.cnt),
+                                          _ptr(self.tgt_ids_dev), self.tgt_ids_host.ctypes.data_as(C.c_void_p),
+                                          len(self.tgt_ids), self.raw.n_clouds, self.raw.total_rows, self.max_tgt_n,
+                                          self.normal_k if self.use_p2l else -1, None, _ptr(self.prepared),
+                                          self.prepared.numel(), st), "prepare_targets")
         elif self.use_p2l:
             check(L.icpmi_normals_2d_batch(_ptr(self.vox.pts), _ptr(self.vox.off), _ptr(self.vox.cnt),
                                            _ptr(self.tgt_ids_dev), len(self.tgt_ids), self.raw.total_rows,

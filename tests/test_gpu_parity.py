@@ -451,3 +451,31 @@ def test_known_motion_recovered(uicp):
         R, t, err, info = batch.icp_batch(srcs, tgts, 1e-16, 300, 1e-7, method=method, normal_k=10)
         worst = max(rot_err(R[i], t[i], Rt, tt) for i, (Rt, tt) in enumerate(truth))
         assert worst < (1e-5 if method == "point_to_point" else 1e-8), (method, worst)
+
+
+def test_submap_10k_target_on_sweep_path(uicp):
+    """BASELINE config 3 shape: one 2 048-beam scan against a ~10 k-point rolling submap (target above the LDS
+    capacity: sorted through global memory, searched through L2).  Must equal the oracle and the exhaustive path."""
+    from icpmi import batch, synth
+    segs = synth.maze_segments()
+    poses = synth.trajectory(90, step=0.35)
+    sub = np.vstack([synth.to_world(synth.scan(p, 500 + i, segs=segs), p) for i, p in enumerate(poses)])
+    sub = oracle.voxel_downsample(sub, 0.04)                     # what _build_submap hands to ICP: ~10 k points
+    assert 9000 < len(sub) < 16000, len(sub)
+    pose = poses[-1]
+    cur = synth.scan(pose, 999, segs=segs)
+    th = pose[2] + np.deg2rad(1.0)
+    R0 = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    t0 = np.array([pose[0] + 0.05, pose[1] - 0.04])
+    for kw in (dict(method="point_to_point", max_corr_dist=1.5), dict(method="point_to_line", normal_k=10)):
+        f = batch.IcpBatch([cur, sub], [0], [1], 1e-10, 150, 0.04, R_init=R0, t_init=t0, **kw)
+        assert f.fast and f.max_tgt_n > 4096
+        f.run()
+        R, t, err, info = f.unpack()
+        Ro, to, eo, io = oracle.icp(cur, sub, 1e-10, 150, 0.04, R_init=R0, t_init=t0, **kw)
+        assert io["n_tgt"] > 4096
+        assert rot_err(R[0], t[0], Ro, to) < FRO_TOL and info["iters"][0] == io["iters"] and info["status"][0] == io["status"]
+        e = batch.IcpBatch([cur, sub], [0], [1], 1e-10, 150, 0.04, R_init=R0, t_init=t0, force_exhaustive=True, **kw)
+        e.run()
+        Re, te, ee, ie = e.unpack()
+        assert ie["iters"][0] == info["iters"][0] and rot_err(R[0], t[0], Re[0], te[0]) < 1e-11
