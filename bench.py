@@ -149,6 +149,7 @@ def main():
         line["single_pair"] = {"ms_per_icp": round(lat * 1e3, 4), "iterations": it1,
                                "iterations_per_sec": round(it1 / lat, 1)}
         line["nn_exhaustive"] = bench_nn_exhaustive(torch, batch, _lib)
+        line["submap"] = bench_submap(torch, synth, not args.no_cpu_baseline)
         if not args.no_raycast:
             line["raycast"] = bench_raycast(torch, synth, args.raycast_scans, not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
@@ -190,6 +191,55 @@ def bench_nn_exhaustive(torch, batch, _lib):
                          "frac": round(gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": byts},
             "valu": {"distance_evals_per_launch": evals, "fp64_ops_per_eval": 6, "achieved_Tops": round(tops, 3),
                      "peak_Tops": FP64_VALU_PEAK_TOPS, "frac": round(tops / FP64_VALU_PEAK_TOPS, 4)}}
+
+
+def bench_submap(torch, synth, with_cpu):
+    """BASELINE config 3: one 2 048-beam scan against a ~10 k-point rolling submap (point_to_point, max_corr_dist 1.5,
+    initial guess = truth perturbed by (0.05, -0.04, 1 deg)), plus the _build_submap voxel filter of 90 x 2 048 points."""
+    from icpmi.batch import CloudSet, IcpBatch, voxel_downsample_set
+    segs = synth.maze_segments()
+    poses = synth.trajectory(90, step=0.35)
+    allpts = np.vstack([synth.to_world(synth.scan(p, 500 + i, segs=segs), p) for i, p in enumerate(poses)])
+    cs = CloudSet.from_numpy([allpts])
+    out = voxel_downsample_set(cs, 0.04)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        voxel_downsample_set(cs, 0.04, out=out)
+    torch.cuda.synchronize()
+    vox_ms = (time.perf_counter() - t0) / 10 * 1e3
+    sub = out.to_numpy()[0]
+    pose = poses[-1]
+    cur = synth.scan(pose, 999, segs=segs)
+    th = pose[2] + np.deg2rad(1.0)
+    R0 = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    t0v = np.array([pose[0] + 0.05, pose[1] - 0.04])
+    kw = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, R_init=R0, t_init=t0v,
+              method="point_to_point", max_corr_dist=1.5)
+    b = IcpBatch([cur, sub], [0], [1], **kw)
+    for _ in range(3):
+        b.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        b.run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    it = float(b.results.cpu().numpy()[0, 14])
+    res = {"workload": f"config 3: 2048-beam scan vs {len(sub)}-point submap, point_to_point, max_corr_dist 1.5",
+           "ms_per_icp": round(ms, 4), "iterations": it, "iterations_per_sec": round(it / (ms * 1e-3), 1),
+           "build_submap_voxel_ms": round(vox_ms, 4), "build_submap_points_in": int(len(allpts))}
+    if with_cpu:
+        import oracle
+        t0 = time.perf_counter()
+        io = oracle.icp(cur, sub, 1e-10, 150, 0.04, R_init=R0, t_init=t0v, method="point_to_point", max_corr_dist=1.5)[3]
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        oracle.voxel_downsample(allpts, 0.04)
+        dv = time.perf_counter() - t0
+        res["cpu_baseline"] = {"ms_per_icp": round(dt * 1e3, 3), "iterations": io["iters"], "build_submap_voxel_ms": round(dv * 1e3, 3),
+                               "cores": 1, "kind": "port"}
+    return res
 
 
 def bench_raycast(torch, synth, n_scans, with_cpu):

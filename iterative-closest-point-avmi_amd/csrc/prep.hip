@@ -15,7 +15,7 @@ constexpr int PREP_MAX_POINTS = 4096;   // sorted copy (20 B/pt) + sort scratch 
 
 // KK = capacity of the per-query neighbour list (0: no normals)
 template <int KK>
-__global__ __launch_bounds__(PREP_THREADS) void prep_targets_kernel(
+__global__ __launch_bounds__(PREP_THREADS, (KK <= 16 ? 4 : 2)) void prep_targets_kernel(   // two workgroups per CU up to KK = 16
     const double* __restrict__ pts, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
     const int32_t* __restrict__ cloud_ids, int k, double2* __restrict__ g_sxy, double2* __restrict__ g_snrm,
     int32_t* __restrict__ g_sorig, int32_t* __restrict__ g_dir, double* __restrict__ out_normals, int lds_points,

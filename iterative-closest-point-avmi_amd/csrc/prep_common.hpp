@@ -53,6 +53,7 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         double s = 0.0;
+#pragma unroll 4
         for (int b = 0; b < PREP_BINS; ++b) { const double cn = (double)hist[d * PREP_BINS + b]; s += cn * cn; }
         const double r = mx[d] - mn[d];
         const double cost = r > 0.0 ? (d < 2 ? 1.0 : 1.4142135623730951) * s / r : __builtin_inf();

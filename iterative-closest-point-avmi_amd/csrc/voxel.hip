@@ -24,12 +24,6 @@ constexpr int VOX_THREADS = 1024;
 constexpr int VOX_MAXW = VOX_THREADS / ICPMI_WAVE;
 constexpr int VOX_SMALL_MAX = 8192;
 
-struct VoxHeader {          // big path: written by vox_bounds_kernel
-    double mn[3];
-    double ext[3];          // key extent per axis (as double), 1 for unused axes
-    int32_t overflow;
-};
-
 __device__ __forceinline__ uint64_t vox_key(const double* p, int dim, const double* mn, const double* ext, double voxel) {
     // floor((p - min) / voxel).astype(int), linearised so that integer order ==
     // lexicographic order of the per-axis keys
@@ -167,36 +161,89 @@ __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
     voxel_finish<DIM>(keys, rows, n, P, O, out_cnt + c, iscratch);
 }
 
-// ── big path ────────────────────────────────────────────────────────────────
+// ── big path: every step spread over the chip ───────────────────────────────
+struct VoxBounds {          // order-preserving uint64 images of the per-axis min / max (atomicMin / atomicMax)
+    unsigned long long mn[3];
+    unsigned long long mx[3];
+};
+
+__global__ void vox_bounds_init_kernel(VoxBounds* b) {
+    if (threadIdx.x < 3) { b->mn[threadIdx.x] = ~0ull; b->mx[threadIdx.x] = 0ull; }
+}
+
 template <int DIM>
-__global__ __launch_bounds__(VOX_THREADS) void vox_bounds_kernel(const double* __restrict__ P, int n, double voxel, VoxHeader* h) {
-    __shared__ double dscratch[6 * VOX_MAXW];
-    double mn[3], mx[3], ext[3];
-    cloud_bounds<DIM>(P, n, mn, mx, dscratch);
-    const bool ok = key_extents<DIM>(mn, mx, voxel, ext);
-    if (threadIdx.x == 0) {
-        for (int d = 0; d < 3; ++d) { h->mn[d] = mn[d]; h->ext[d] = ext[d]; }
-        h->overflow = ok ? 0 : 1;
+__global__ __launch_bounds__(256) void vox_bounds_kernel(const double* __restrict__ P, int n, VoxBounds* b) {
+    double mn[DIM], mx[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) { mn[d] = __builtin_inf(); mx[d] = -__builtin_inf(); }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            const double v = P[(size_t)i * DIM + d];
+            mn[d] = fmin(mn[d], v);
+            mx[d] = fmax(mx[d], v);
+        }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        const double a = wave_min(mn[d]), c = wave_max(mx[d]);
+        if (lane_id() == 0) {
+            atomicMin(&b->mn[d], (unsigned long long)f64_sortable(a));
+            atomicMax(&b->mx[d], (unsigned long long)f64_sortable(c));
+        }
     }
 }
 
 template <int DIM>
-__global__ void vox_keys_kernel(const double* __restrict__ P, int n, double voxel, const VoxHeader* __restrict__ h,
-                                uint64_t* __restrict__ keys, uint32_t* __restrict__ rows) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double mn[3] = {h->mn[0], h->mn[1], h->mn[2]}, ext[3] = {h->ext[0], h->ext[1], h->ext[2]};
-    keys[i] = h->overflow ? 0ull : vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel);
-    rows[i] = (uint32_t)i;
+__device__ __forceinline__ bool vox_header(const VoxBounds* __restrict__ b, double voxel, double (&mn)[3], double (&ext)[3]) {
+    double mx[3];
+    for (int d = 0; d < 3; ++d) { mn[d] = 0.0; mx[d] = 0.0; }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) { mn[d] = f64_unsortable(b->mn[d]); mx[d] = f64_unsortable(b->mx[d]); }
+    return key_extents<DIM>(mn, mx, voxel, ext);
 }
 
 template <int DIM>
-__global__ __launch_bounds__(VOX_THREADS) void vox_finish_kernel(const uint64_t* keys, const uint32_t* rows, int n,
-                                                                 const double* __restrict__ P, double* __restrict__ O,
-                                                                 int32_t* out_cnt, const VoxHeader* __restrict__ h) {
-    __shared__ int iscratch[VOX_MAXW];
-    if (h->overflow) { if (threadIdx.x == 0) *out_cnt = -1; return; }
-    voxel_finish<DIM>(keys, rows, n, P, O, out_cnt, iscratch);
+__global__ void vox_keys_kernel(const double* __restrict__ P, int n, double voxel, const VoxBounds* __restrict__ b,
+                                uint64_t* __restrict__ keys, uint32_t* __restrict__ rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double mn[3], ext[3];
+    const bool ok = vox_header<DIM>(b, voxel, mn, ext);
+    keys[i] = ok ? vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel) : 0ull;
+    rows[i] = (uint32_t)i;
+}
+
+// 1 where a new voxel starts in the sorted order
+__global__ void vox_heads_kernel(const uint64_t* __restrict__ keys, int n, uint32_t* __restrict__ heads) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) heads[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+
+// one thread per voxel head: in-order sum over its run of equal keys, mean, voxel id from the scan
+template <int DIM>
+__global__ void vox_means_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ rows,
+                                 const uint32_t* __restrict__ heads, const uint32_t* __restrict__ vid, int n, double voxel,
+                                 const VoxBounds* __restrict__ b, const double* __restrict__ P, double* __restrict__ O,
+                                 int32_t* __restrict__ out_cnt) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    double mn[3], ext[3];
+    const bool ok = vox_header<DIM>(b, voxel, mn, ext);
+    if (r == n - 1) *out_cnt = ok ? (int32_t)(vid[r] + heads[r]) : -1;
+    if (!ok || !heads[r]) return;
+    const uint64_t k = keys[r];
+    double s[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) s[d] = 0.0;
+    int q = r;
+    for (; q < n && keys[q] == k; ++q) {                     // rows ascending == input order
+        const double* p = P + (size_t)rows[q] * DIM;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) s[d] += p[d];
+    }
+    const double c = (double)(q - r);
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) O[(size_t)vid[r] * DIM + d] = s[d] / c;
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -209,21 +256,39 @@ static size_t radix_temp_bytes(int n) {
     return bytes;
 }
 
+static size_t scan_temp_bytes(int n) {
+    size_t bytes = 0;
+    uint32_t* v = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, bytes, v, v, 0u, (size_t)n, rocprim::plus<uint32_t>(), (hipStream_t)0, false);
+    return bytes;
+}
+
+static size_t voxel_big_bytes(int n) {
+    const size_t t1 = radix_temp_bytes(n), t2 = scan_temp_bytes(n);
+    return 256 + 2 * align256((size_t)n * 8) + 4 * align256((size_t)n * 4) + align256(t1 > t2 ? t1 : t2) + 256;
+}
+
 template <int DIM>
 static int voxel_big(const double* P, int n, double voxel, double* O, int32_t* out_cnt, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (ws_bytes < voxel_big_bytes(n)) return ICPMI_ERR_WORKSPACE;
     unsigned char* base = (unsigned char*)ws;
     size_t o = 0;
-    VoxHeader* h = (VoxHeader*)(base + o); o += 256;
+    VoxBounds* h = (VoxBounds*)(base + o); o += 256;
     uint64_t* k0 = (uint64_t*)(base + o); o += align256((size_t)n * 8);
     uint64_t* k1 = (uint64_t*)(base + o); o += align256((size_t)n * 8);
     uint32_t* r0 = (uint32_t*)(base + o); o += align256((size_t)n * 4);
     uint32_t* r1 = (uint32_t*)(base + o); o += align256((size_t)n * 4);
-    size_t tb = radix_temp_bytes(n);
-    if (o + tb > ws_bytes) return ICPMI_ERR_WORKSPACE;
-    vox_bounds_kernel<DIM><<<1, VOX_THREADS, 0, st>>>(P, n, voxel, h);
-    vox_keys_kernel<DIM><<<(n + 255) / 256, 256, 0, st>>>(P, n, voxel, h, k0, r0);
+    uint32_t* heads = (uint32_t*)(base + o); o += align256((size_t)n * 4);
+    uint32_t* vid = (uint32_t*)(base + o); o += align256((size_t)n * 4);
+    size_t tb = radix_temp_bytes(n), sb = scan_temp_bytes(n);
+    const int blocks = (n + 255) / 256;
+    vox_bounds_init_kernel<<<1, 64, 0, st>>>(h);
+    vox_bounds_kernel<DIM><<<blocks < 1024 ? blocks : 1024, 256, 0, st>>>(P, n, h);
+    vox_keys_kernel<DIM><<<blocks, 256, 0, st>>>(P, n, voxel, h, k0, r0);
     if (rocprim::radix_sort_pairs(base + o, tb, k0, k1, r0, r1, (size_t)n, 0, 64, st, false) != hipSuccess) return ICPMI_ERR_HIP;
-    vox_finish_kernel<DIM><<<1, VOX_THREADS, 0, st>>>(k1, r1, n, P, O, out_cnt, h);
+    vox_heads_kernel<<<blocks, 256, 0, st>>>(k1, n, heads);
+    if (rocprim::exclusive_scan(base + o, sb, heads, vid, 0u, (size_t)n, rocprim::plus<uint32_t>(), st, false) != hipSuccess) return ICPMI_ERR_HIP;
+    vox_means_kernel<DIM><<<blocks, 256, 0, st>>>(k1, r1, heads, vid, n, voxel, h, P, O, out_cnt);
     ICPMI_LAUNCH_CHECK();
     return ICPMI_OK;
 }
@@ -233,7 +298,7 @@ static int voxel_big(const double* P, int n, double voxel, double* O, int32_t* o
 extern "C" size_t icpmi_voxel_workspace_bytes(int32_t max_n) {
     using namespace icpmi;
     if (max_n <= VOX_SMALL_MAX) return 256;
-    return 256 + 2 * align256((size_t)max_n * 8) + 2 * align256((size_t)max_n * 4) + align256(radix_temp_bytes(max_n)) + 256;
+    return voxel_big_bytes(max_n);
 }
 
 extern "C" int icpmi_voxel_downsample_batch(const double* pts, const int32_t* off_dev, const int32_t* off_host,
