@@ -169,6 +169,15 @@ int icpmi_nn_prepared_batch(const double* pts, const int32_t* off_dev, const int
                             int32_t* out_idx, double* out_dist, double* out_second_sq,
                             int32_t out_stride, void* stream);
 
+/* ---- rotation search scoring, utilities/features.py:213-232 (and slam.py:138-159) ----
+ * For every angle a (given as cos, sin pairs — computed by the caller with the
+ * reference's own NumPy calls): mean over the rows of src_c of the squared
+ * nearest-neighbour distance of (src_c @ R(a).T + shift) in tgt, R = [[c,-s],[s,c]].
+ * One launch for a whole sweep.  src_c: (n_src, 2), tgt: (n_tgt, 2), row-major. */
+int icpmi_rotation_scores(const double* src_c, int32_t n_src, const double* tgt, int32_t n_tgt,
+                          const double* cos_sin, int32_t n_angles, double shift_x, double shift_y,
+                          double* out_scores, void* stream);
+
 /* ---- OccupancyGrid2D, utilities/mapping.py ---------------------------------
  * world -> cell index, mapping.py:57-60,94-98: floor((w - min) / res), float64
  * IEEE division, result as int64. */

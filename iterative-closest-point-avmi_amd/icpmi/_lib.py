@@ -59,6 +59,8 @@ _SIGS = {
                                         C.c_void_p]),
     "icpmi_nn_prepared_batch": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int32, C.c_void_p]),
+    "icpmi_rotation_scores": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double,
+                                        C.c_double, C.c_void_p, C.c_void_p]),
     "icpmi_world_to_grid": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "icpmi_bresenham_cells": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "icpmi_grid_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

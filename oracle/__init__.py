@@ -61,6 +61,8 @@ def lib():
                                            C.c_double, C.c_double, dp, C.c_int,
                                            C.c_double, C.c_double, C.c_double, C.c_double]
         L.orc_grid_update_scan.restype = C.c_int64
+        L.orc_rotation_scores.argtypes = [dp, C.c_int, dp, C.c_int, dp, C.c_int, C.c_double, C.c_double, dp]
+        L.orc_rotation_scores.restype = None
         _lib = L
     return _lib
 
@@ -164,3 +166,30 @@ def grid_update_scan(log_odds, min_x, min_y, res, origin_xy, hits, l_hit, l_miss
     return lib().orc_grid_update_scan(_p(log_odds, C.c_float), ny, nx, float(min_x), float(min_y), float(res),
                                       float(origin_xy[0]), float(origin_xy[1]), _p(h), len(h),
                                       float(l_hit), float(l_miss), float(lo), float(hi))
+
+
+def rotation_scores(src_c, tgt, angles, shift):
+    """features.py:213-218 `_score` for every angle (radians): mean squared NN distance of src_c @ R(a).T + shift."""
+    s, t = _d(src_c), _d(tgt)
+    a = np.ascontiguousarray(angles, dtype=np.float64)
+    cs = np.ascontiguousarray(np.stack([np.cos(a), np.sin(a)], axis=1))
+    out = np.empty(len(a))
+    lib().orc_rotation_scores(_p(s), len(s), _p(t), len(t), _p(cs), len(a), float(shift[0]), float(shift[1]), _p(out))
+    return out
+
+
+def rotation_search(source, target, voxel_size=0.3, angle_step_coarse=2.0, angle_step_fine=0.2):
+    """Restatement of features.py:165-242 on top of the oracle's voxel filter and scoring -> (R, t, score)."""
+    src, tgt = voxel_downsample(source, voxel_size), voxel_downsample(target, voxel_size)
+    if len(src) < 5 or len(tgt) < 5:
+        return np.eye(2), np.zeros(2), float("inf")
+    mu_s, mu_t = src.mean(axis=0), tgt.mean(axis=0)
+    src_c = src - mu_s
+    coarse = np.deg2rad(np.arange(-180, 180, angle_step_coarse))
+    best = coarse[int(np.argmin(rotation_scores(src_c, tgt, coarse, mu_t)))]
+    fine = np.arange(best - np.deg2rad(angle_step_coarse), best + np.deg2rad(angle_step_coarse), np.deg2rad(angle_step_fine))
+    sf = rotation_scores(src_c, tgt, fine, mu_t)
+    i = int(np.argmin(sf))
+    ca, sa = np.cos(fine[i]), np.sin(fine[i])
+    R = np.array([[ca, -sa], [sa, ca]])
+    return R, mu_t - R @ mu_s, sf[i]

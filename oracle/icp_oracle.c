@@ -543,3 +543,30 @@ int64_t orc_grid_update_scan(float* log_odds, int ny, int nx, double min_x, doub
     free(hx); free(hy);
     return updates;
 }
+
+/* ------------------------------------------------------------------------- */
+/* rotation_search scoring — reference utilities/features.py:213-218          */
+/* ------------------------------------------------------------------------- */
+/* score[a] = mean over rows of (NN distance)^2 of (src_c @ R(a).T + shift) in tgt, with
+ * R(a) = [[c,-s],[s,c]] given as cs[2a], cs[2a+1]; distance = sqrt(d2) squared again,
+ * as the reference's `np.mean(dists ** 2)` on KDTree distances. */
+void orc_rotation_scores(const double* src_c, int n, const double* tgt, int m, const double* cs, int n_angles,
+                         double shift_x, double shift_y, double* scores) {
+    kdt_t* t = orc_kd_create(tgt, m, 2);
+    double* rot = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1) * 2);
+    int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    double* d2 = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int a = 0; a < n_angles; ++a) {
+        const double c = cs[2 * a], s = cs[2 * a + 1];
+        for (int i = 0; i < n; ++i) {
+            const double x = src_c[2 * i], y = src_c[2 * i + 1];
+            rot[2 * i] = (x * c + y * -s) + shift_x;
+            rot[2 * i + 1] = (x * s + y * c) + shift_y;
+        }
+        orc_kd_knn(t, rot, n, 1, idx, d2);
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) { const double d = sqrt(d2[i]); acc += d * d; }
+        scores[a] = acc / (double)n;
+    }
+    free(rot); free(idx); free(d2); orc_kd_destroy(t);
+}

@@ -303,6 +303,29 @@ def gold_submap_build():
          in_head=allpts[:8], out=sub)
 
 
+# ── 9. rotation search (features.py:165-242; needs the package import for its relative import) ──
+def gold_rotation_search():
+    sys.path.insert(0, REF)
+    import importlib
+    ref_feat = importlib.import_module("utilities.features")       # the REFERENCE's utilities package (pyvista stubbed)
+    a, b = synth.config2_pair(0)
+    out = {}
+    cases = {"cfg": (a, b, dict(voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)),
+             "default": (a, b, dict())}
+    th = np.deg2rad(137.0)
+    Rbig = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    cases["big_rotation"] = (a, b @ Rbig.T + np.array([1.5, -0.7]), dict(voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1))
+    cases["tiny"] = (a[:4], b, dict())
+    for k, (s, t, kw) in cases.items():
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            R, tt, score = ref_feat.rotation_search(s, t, **kw)
+        out[f"{k}__src"], out[f"{k}__tgt"] = s, t
+        out[f"{k}__R"], out[f"{k}__t"], out[f"{k}__score"] = R, tt, np.float64(score)
+        out[f"{k}__kw"] = np.array([kw.get("voxel_size", 0.3), kw.get("angle_step_coarse", 2.0), kw.get("angle_step_fine", 0.2)])
+    save("rotation_search", **out)
+
+
 if __name__ == "__main__":
     gold_voxel()
     sub = gold_nn()
@@ -312,3 +335,4 @@ if __name__ == "__main__":
     gold_bresenham()
     gold_grid()
     gold_submap_build()
+    gold_rotation_search()

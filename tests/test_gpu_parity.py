@@ -479,3 +479,33 @@ def test_submap_10k_target_on_sweep_path(uicp):
         e.run()
         Re, te, ee, ie = e.unpack()
         assert ie["iters"][0] == info["iters"][0] and rot_err(R[0], t[0], Re[0], te[0]) < 1e-11
+
+
+# ── rotation search ─────────────────────────────────────
+@pytest.mark.parametrize("case", ["cfg", "default", "big_rotation", "tiny"])
+def test_rotation_search_golden(uicp, case, capsys):
+    from utilities import features
+    z = load_golden("rotation_search")
+    kw = z[f"{case}__kw"]
+    R, t, s = features.rotation_search(z[f"{case}__src"], z[f"{case}__tgt"], kw[0], kw[1], kw[2])
+    assert np.array_equal(R, z[f"{case}__R"]) and np.array_equal(t, z[f"{case}__t"])   # same arg-min on the same grid
+    ref = float(z[f"{case}__score"])
+    assert (np.isinf(s) and np.isinf(ref)) or abs(s - ref) < 1e-13
+    if case != "tiny":
+        assert "Rotation search: best angle" in capsys.readouterr().out
+
+
+def test_rotation_scores_against_oracle(uicp):
+    from icpmi import synth
+    from utilities import features
+    rng = np.random.default_rng(12)
+    a, b = synth.config2_pair(5)
+    src = uicp.voxel_downsample(a, 0.15)
+    tgt = uicp.voxel_downsample(b, 0.15)
+    angles = np.deg2rad(np.arange(-180, 180, 1.5))
+    for s_, t_, shift in ((src - src.mean(0), tgt, tgt.mean(0)), (rng.normal(size=(700, 2)), rng.normal(size=(5000, 2)), (0.3, -0.1)),
+                          (rng.normal(size=(1, 2)), rng.normal(size=(3, 2)), (0.0, 0.0))):
+        got = features.rotation_scores(s_, t_, angles, shift)
+        ref = oracle.rotation_scores(s_, t_, angles, shift)
+        assert np.abs(got - ref).max() <= 1e-13 * max(1.0, ref.max())
+        assert int(np.argmin(got)) == int(np.argmin(ref))

@@ -195,3 +195,14 @@ def test_build_submap_voxel():
     assert len(allpts) == int(z["n_in"]) and np.array_equal(allpts[:8], z["in_head"])
     out = oracle.voxel_downsample(allpts, 0.04)
     assert np.array_equal(out, z["out"])
+
+
+@pytest.mark.parametrize("case", ["cfg", "default", "big_rotation", "tiny"])
+def test_rotation_search_matches_reference(case):
+    """features.py:165-242: same angle grid, same arg-min, so R and t are bit-equal; score to rounding."""
+    z = load_golden("rotation_search")
+    kw = z[f"{case}__kw"]
+    R, t, s = oracle.rotation_search(z[f"{case}__src"], z[f"{case}__tgt"], kw[0], kw[1], kw[2])
+    assert np.array_equal(R, z[f"{case}__R"]) and np.array_equal(t, z[f"{case}__t"])
+    ref = float(z[f"{case}__score"])
+    assert (np.isinf(s) and np.isinf(ref)) or abs(s - ref) < 1e-14
