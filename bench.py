@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=512)
+    ap.add_argument("--pairs-total", type=int, default=0,
+                    help="strong scaling: this many pairs in all, split over the GPUs (BASELINE config 5 uses 512)")
     ap.add_argument("--raycast-scans", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raycast", action="store_true")
@@ -64,6 +66,10 @@ def main():
 
     # ── workload: distinct pairs per rank, inputs resident in HBM before timing ──
     B = args.pairs_per_gpu
+    if args.pairs_total:
+        if args.pairs_total % world:
+            raise SystemExit("--pairs-total must be a multiple of the number of GPUs")
+        B = args.pairs_total // world
     srcs, tgts = synth.loop_closure_batch(B, seed0=1000 + 100003 * rank)
     batch = IcpBatch(srcs + tgts, np.arange(B), np.arange(B, 2 * B), **ICP_KW)
     n_total = B * world
@@ -124,7 +130,8 @@ def main():
 
     line = {"metric": "icp_iterations_per_sec", "value": round(value, 1), "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "strong" if args.pairs_total else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config 2 scan pairs (2048-beam room scans, point_to_line ICP, voxel 0.04, "
                                    "normal_k 12, thr 1e-10) batched as in config 5",
@@ -150,6 +157,7 @@ def main():
                                "iterations_per_sec": round(it1 / lat, 1)}
         line["nn_exhaustive"] = bench_nn_exhaustive(torch, batch, _lib)
         line["submap"] = bench_submap(torch, synth, not args.no_cpu_baseline)
+        line["scan_pair_host_api"] = bench_host_api(srcs[0], tgts[0], not args.no_cpu_baseline)
         if not args.no_raycast:
             line["raycast"] = bench_raycast(torch, synth, args.raycast_scans, not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
@@ -191,6 +199,40 @@ def bench_nn_exhaustive(torch, batch, _lib):
                          "frac": round(gbs / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_launch": byts},
             "valu": {"distance_evals_per_launch": evals, "fp64_ops_per_eval": 6, "achieved_Tops": round(tops, 3),
                      "peak_Tops": FP64_VALU_PEAK_TOPS, "frac": round(tops / FP64_VALU_PEAK_TOPS, 4)}}
+
+
+def bench_host_api(src, tgt, with_cpu):
+    """What slam.py's _run_icp_pair does per loop-closure candidate (slam.py:53-98, config.yaml:19-39), through the
+    drop-in NumPy-in / NumPy-out functions: rotation_search (240 + ~30 angles) then point_to_line ICP with its
+    result as the initial guess.  PCIe and host round trips included — never the headline value."""
+    from utilities import features, icp as uicp
+    uicp.VERBOSE = features.VERBOSE = False
+    kw = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+
+    def pair():
+        R0, t0, _ = features.rotation_search(src, tgt, voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
+        return uicp.ICP(src, tgt, R_init=R0, t_init=t0, **kw)
+
+    pair()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        features.rotation_search(src, tgt, voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
+    rs_ms = (time.perf_counter() - t0) / 20 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(20):
+        pair()
+    pair_ms = (time.perf_counter() - t0) / 20 * 1e3
+    out = {"rotation_search_ms": round(rs_ms, 3), "run_icp_pair_ms": round(pair_ms, 3),
+           "reference_python_ms": {"rotation_search": 73.0, "run_icp_pair": 149.0,
+                                   "note": "survey container, 1 core (BASELINE.md section 2), not this box"}}
+    if with_cpu:
+        import oracle
+        t0 = time.perf_counter()
+        for _ in range(5):
+            R0, tt0, _ = oracle.rotation_search(src, tgt, 0.15, 1.5, 0.1)
+            oracle.icp(src, tgt, R_init=R0, t_init=tt0, **kw)
+        out["cpu_baseline_run_icp_pair_ms"] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    return out
 
 
 def bench_submap(torch, synth, with_cpu):
