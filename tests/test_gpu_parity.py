@@ -509,3 +509,36 @@ def test_rotation_scores_against_oracle(uicp):
         ref = oracle.rotation_scores(s_, t_, angles, shift)
         assert np.abs(got - ref).max() <= 1e-13 * max(1.0, ref.max())
         assert int(np.argmin(got)) == int(np.argmin(ref))
+
+
+# ── device-resident rolling submap ──────────────────────
+def test_rolling_submap_equals_build_submap(uicp):
+    """slam.py:103-108 + 559-562: 40-scan window, vstack + voxel filter, then scan-to-submap ICP (slam.py:217-225)."""
+    from icpmi import synth
+    from icpmi.submap import RollingSubmap
+    z = load_golden("submap_build")
+    segs = synth.maze_segments()
+    poses = synth.trajectory(46)
+    scans = [synth.to_world(synth.scan(p, 500 + i, segs=segs), p) for i, p in enumerate(poses)]
+    sm = RollingSubmap(window=40, voxel_size=0.04)
+    for s in scans[:40]:
+        sm.push(s)
+    assert len(sm) == 40 and sm.points_in == int(z["n_in"])
+    assert np.array_equal(sm.build_numpy(), z["out"])                 # golden captured from the reference
+    for s in scans[40:]:                                              # window slides: oldest scans drop out
+        sm.push(s)
+    assert len(sm) == 40
+    assert np.array_equal(sm.build_numpy(), oracle.voxel_downsample(np.vstack(scans[6:46]), 0.04))
+    sm.reset(scans[:10])
+    assert np.array_equal(sm.build_numpy(), oracle.voxel_downsample(np.vstack(scans[:10]), 0.04))
+    # scan-to-submap ICP against the resident submap
+    sm.reset(scans[:40])
+    pose = poses[39]
+    cur = synth.scan(pose, 999, segs=segs)
+    th = pose[2] + np.deg2rad(1.0)
+    R0 = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    t0 = np.array([pose[0] + 0.05, pose[1] - 0.04])
+    R, t, err, info = sm.icp(cur, 1e-10, 150, 0.04, R_init=R0, t_init=t0, method="point_to_point", max_corr_dist=1.5)
+    Ro, to, eo, io = oracle.icp(cur, z["out"], 1e-10, 150, 0.04, R_init=R0, t_init=t0, method="point_to_point", max_corr_dist=1.5)
+    assert rot_err(R, t, Ro, to) < FRO_TOL and info["iters"] == io["iters"]
+    assert RollingSubmap(window=3).build_numpy().shape == (0, 2)
