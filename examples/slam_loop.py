@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""A minimal scan-matching + mapping loop on the drop-in API.
+
+Not a port of the reference's slam.py (its pose graph, display and services are out of scope): a
+fresh harness with the same per-scan shape (slam.py:377-640) that shows the accelerated path working
+end to end on a synthetic drive:
+
+    scan-to-scan:   rotation_search -> ICP(point_to_line)                 slam.py:53-98, 481-483
+    pose update:    global_pose @ inverse(T)                              slam.py:38-43, 494
+    submap:         RollingSubmap.icp(point_to_point, max_corr_dist)      slam.py:186-225, 505-536
+    mapping:        OccupancyGrid2D.update_scan                           slam.py:552-557
+    loop closure:   batched ICP of the current scan against old scans     slam.py:566-597
+
+It also writes and re-reads the drive in the reference's lidar wire format
+(`timestamp_us;x1;y1;z1;x2;...`, services/lidar_service.py:5-19).
+
+    python examples/slam_loop.py [n_scans]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "iterative-closest-point-avmi_amd"))
+
+from icpmi import batch, synth  # noqa: E402
+from icpmi.submap import RollingSubmap  # noqa: E402
+from utilities import features  # noqa: E402
+from utilities import icp as uicp  # noqa: E402
+from utilities.mapping import OccupancyGrid2D  # noqa: E402
+
+
+# ── reference wire format ────────────────────────────────────────────────────
+def write_lidar_log(path, scans, dt_us=100000, z=1.0):
+    """One line per scan: timestamp_us;x;y;z;x;y;z;... (sensor frame)."""
+    with open(path, "w") as f:
+        for i, s in enumerate(scans):
+            xyz = np.column_stack([s, np.full(len(s), z)])
+            f.write(str(1000000 + i * dt_us) + ";" + ";".join(repr(float(v)) for v in xyz.ravel()) + "\n")
+
+
+def read_lidar_log(path, z_min=0.2, z_max=2.0):
+    """Yield (timestamp_us, points_xy): all-zero triples dropped, z-slice kept (slam.py:24-27)."""
+    with open(path) as f:
+        for line in f:
+            el = line.strip().replace(";", " ").split()
+            ts = int(el[0])
+            p = np.array(el[1:], dtype=np.float64).reshape(-1, 3)
+            p = p[~np.all(p == 0, axis=1)]
+            keep = (p[:, 2] >= z_min) & (p[:, 2] <= z_max)
+            yield ts, np.ascontiguousarray(p[keep, :2])
+
+
+def pose_matrix(x, y, th):
+    c, s = np.cos(th), np.sin(th)
+    return np.array([[c, -s, x], [s, c, y], [0.0, 0.0, 1.0]])
+
+
+def run(n_scans=60, log_path=None, verbose=True):
+    uicp.VERBOSE = features.VERBOSE = False
+    segs = synth.maze_segments()
+    truth = synth.trajectory(n_scans, step=0.18)
+    scans = [synth.scan(p, 9000 + i, segs=segs) for i, p in enumerate(truth)]
+    if log_path:
+        write_lidar_log(log_path, scans)
+        scans = [pts for _, pts in read_lidar_log(log_path)]
+    icp_kw = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+    pose = pose_matrix(*truth[0])                       # start at the true pose; everything after is estimated
+    submap = RollingSubmap(window=40, voxel_size=0.04)
+    history, mapper, timing = [], None, {"s2s": 0.0, "submap": 0.0, "map": 0.0, "loop": 0.0}
+    closures, rejected = [], []
+    prev = None
+    for i, cur in enumerate(scans):
+        if prev is not None:
+            t0 = time.perf_counter()
+            # ICP(prev -> cur) maps the previous scan into the current sensor frame (slam.py:481-483)
+            R0, t0v, _ = features.rotation_search(prev, cur, voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
+            r, t, err = uicp.ICP(prev, cur, R_init=R0, t_init=t0v, **icp_kw)
+            if err <= 0.15:                                                   # error_reject_threshold, slam.py:485-490
+                T_inv = np.eye(3)
+                T_inv[:2, :2] = r.T
+                T_inv[:2, 2] = -r.T @ t
+                pose = pose @ T_inv                                           # slam.py:38-43
+            else:
+                rejected.append(i)                                            # keep the pose; the submap step may still fix it
+            timing["s2s"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            if len(submap) >= 5:                                              # slam.py:505-536
+                Rs, ts, es, info = submap.icp(cur, 1e-10, 150, 0.04, R_init=pose[:2, :2], t_init=pose[:2, 2],
+                                              method="point_to_point", max_corr_dist=1.5)
+                dpos = np.linalg.norm(ts - pose[:2, 2])
+                dyaw = abs(np.arctan2(Rs[1, 0], Rs[0, 0]) - np.arctan2(pose[1, 0], pose[0, 0]))
+                if np.isfinite(es) and dpos < 1.5 and dyaw < np.deg2rad(15):
+                    pose[:2, :2], pose[:2, 2] = Rs, ts
+            timing["submap"] += time.perf_counter() - t0
+        world = cur @ pose[:2, :2].T + pose[:2, 2]
+        t0 = time.perf_counter()
+        if mapper is None:                                                    # slam.py:398-408
+            mapper = OccupancyGrid2D(world[:, 0].min() - 50, world[:, 0].max() + 50, world[:, 1].min() - 50,
+                                     world[:, 1].max() + 50, resolution=0.05, p_hit=0.85, p_miss=0.42,
+                                     log_odds_min=-8.0, log_odds_max=8.0)
+        mapper.update_scan(pose[:2, 2], world)
+        timing["map"] += time.perf_counter() - t0
+        submap.push(world)
+        history.append((cur, pose.copy()))
+        # loop closure candidates: old scans near the current position, all registered in one batch (slam.py:566-597)
+        t0 = time.perf_counter()
+        if i >= 30 and i % 10 == 0:
+            cands = [k for k, (_, pk) in enumerate(history[:-20]) if np.linalg.norm(pk[:2, 2] - pose[:2, 2]) < 3.0][:16]
+            if cands:
+                R, t, err, info = batch.icp_batch(cur, [history[k][0] for k in cands], **icp_kw)
+                best = int(np.argmin(err))
+                closures.append((i, cands[best], float(err[best]), int(info["iters"][best])))
+        timing["loop"] += time.perf_counter() - t0
+        prev = cur
+    est = np.array([p[:2, 2] for _, p in history])
+    gt = np.array([[p[0], p[1]] for p in truth])
+    drift = np.linalg.norm(est - gt, axis=1)
+    occupied = int((mapper.log_odds > 0).sum())
+    free = int((mapper.log_odds < 0).sum())
+    if verbose:
+        print(f"{n_scans} scans: final position error {drift[-1]:.3f} m (max {drift.max():.3f} m over {np.sum(np.linalg.norm(np.diff(gt, axis=0), axis=1)):.1f} m driven)")
+        print(f"map: {occupied} occupied / {free} free cells; scan-to-scan rejections at {rejected}; loop-closure checks: {closures}")
+        print("wall ms per scan: " + ", ".join(f"{k} {v / n_scans * 1e3:.2f}" for k, v in timing.items()))
+    return dict(drift=drift, occupied=occupied, free=free, closures=closures, rejected=rejected, timing=timing)
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, log_path="/tmp/icpmi_demo_lidar.csv")

@@ -1,0 +1,44 @@
+"""The SLAM-loop harness of examples/ (SURVEY §8f rank 3): wire format on CPU, the loop itself on the GPU."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def _load():
+    spec = importlib.util.spec_from_file_location("slam_loop", os.path.join(REPO, "examples", "slam_loop.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_lidar_wire_format_round_trip(tmp_path):
+    """services/lidar_service.py:5-19: `timestamp;x;y;z;...` lines, all-zero triples dropped, z slice kept."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.importorskip("icpmi")       # the harness imports the drop-in modules; they import without a GPU
+    m = _load()
+    rng = np.random.default_rng(0)
+    scans = [rng.normal(size=(n, 2)) for n in (5, 1, 17)]
+    scans[0][2] = 0.0                                   # a (0, 0) return survives: z = 1 keeps the triple non-zero
+    path = tmp_path / "lidar.csv"
+    m.write_lidar_log(str(path), scans)
+    back = list(m.read_lidar_log(str(path)))
+    assert [t for t, _ in back] == [1000000, 1100000, 1200000]
+    for (_, got), ref in zip(back, scans):
+        assert np.array_equal(got, ref)                 # repr() round-trips float64 exactly
+    with open(path, "a") as f:
+        f.write("1300000;0;0;0;1.5;2.5;0.1;3.0;4.0;1.0\n")   # zero triple dropped, z = 0.1 outside the slice
+    assert np.array_equal(list(m.read_lidar_log(str(path)))[-1][1], [[3.0, 4.0]])
+
+
+@pytest.mark.gpu
+def test_slam_loop_tracks_the_drive(tmp_path):
+    m = _load()
+    out = m.run(36, log_path=str(tmp_path / "drive.csv"), verbose=False)
+    assert out["drift"].max() < 0.25, out["drift"].max()          # metres, over ~6.5 m driven with 1 cm range noise
+    assert out["occupied"] > 1000 and out["free"] > 50000
+    assert out["closures"] == [] or all(np.isfinite(c[2]) for c in out["closures"])
