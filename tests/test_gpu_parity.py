@@ -487,7 +487,11 @@ def test_rotation_search_golden(uicp, case, capsys):
     from utilities import features
     z = load_golden("rotation_search")
     kw = z[f"{case}__kw"]
-    R, t, s = features.rotation_search(z[f"{case}__src"], z[f"{case}__tgt"], kw[0], kw[1], kw[2])
+    features.VERBOSE = True                                   # the reference prints one line per search
+    try:
+        R, t, s = features.rotation_search(z[f"{case}__src"], z[f"{case}__tgt"], kw[0], kw[1], kw[2])
+    finally:
+        features.VERBOSE = False
     assert np.array_equal(R, z[f"{case}__R"]) and np.array_equal(t, z[f"{case}__t"])   # same arg-min on the same grid
     ref = float(z[f"{case}__score"])
     assert (np.isinf(s) and np.isinf(ref)) or abs(s - ref) < 1e-13
@@ -542,3 +546,25 @@ def test_rolling_submap_equals_build_submap(uicp):
     Ro, to, eo, io = oracle.icp(cur, z["out"], 1e-10, 150, 0.04, R_init=R0, t_init=t0, method="point_to_point", max_corr_dist=1.5)
     assert rot_err(R, t, Ro, to) < FRO_TOL and info["iters"] == io["iters"]
     assert RollingSubmap(window=3).build_numpy().shape == (0, 2)
+
+
+def test_icp_fast_path_shapes(uicp):
+    """Every instantiation of the fast kernel: <=1024 / <=2048 / <=4096 source rows x target in LDS / through L2."""
+    from icpmi import batch, synth
+    rng = np.random.default_rng(6)
+    segs = synth.maze_segments()
+    world = np.vstack([synth.to_world(synth.scan(p, 70 + i, segs=segs), p) for i, p in enumerate(synth.trajectory(8))])
+    th = np.deg2rad(1.2)
+    Rm = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    for n_src in (700, 1800, 3500):
+        for n_tgt in (3000, 9000):
+            tgt = world[rng.permutation(len(world))[:n_tgt]]
+            src = (world[rng.permutation(len(world))[:n_src]] - np.array([0.04, 0.03])) @ Rm.T
+            for method in ("point_to_line", "point_to_point"):
+                kw = dict(method=method, normal_k=8, max_corr_dist=0.8)
+                b = batch.IcpBatch([src, tgt], [0], [1], 1e-10, 80, 0.01, **kw)      # voxel 0.01 keeps nearly every point
+                assert b.fast
+                b.run()
+                R, t, err, info = b.unpack()
+                Ro, to, eo, io = oracle.icp(src, tgt, 1e-10, 80, 0.01, **kw)
+                assert rot_err(R[0], t[0], Ro, to) < FRO_TOL and info["iters"][0] == io["iters"], (n_src, n_tgt, method)
