@@ -283,7 +283,8 @@ static int voxel_big(const double* P, int n, double voxel, double* O, int32_t* o
     size_t tb = radix_temp_bytes(n), sb = scan_temp_bytes(n);
     const int blocks = (n + 255) / 256;
     vox_bounds_init_kernel<<<1, 64, 0, st>>>(h);
-    vox_bounds_kernel<DIM><<<blocks < 1024 ? blocks : 1024, 256, 0, st>>>(P, n, h);
+    // few workgroups: every wave ends with 2*DIM atomics on the same words, and those serialise
+    vox_bounds_kernel<DIM><<<blocks < 64 ? blocks : 64, 256, 0, st>>>(P, n, h);
     vox_keys_kernel<DIM><<<blocks, 256, 0, st>>>(P, n, voxel, h, k0, r0);
     if (rocprim::radix_sort_pairs(base + o, tb, k0, k1, r0, r1, (size_t)n, 0, 64, st, false) != hipSuccess) return ICPMI_ERR_HIP;
     vox_heads_kernel<<<blocks, 256, 0, st>>>(k1, n, heads);

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(REPO, "iterative-closest-point-avmi_amd"))
 import numpy as np, torch
 from icpmi import synth
 from icpmi.batch import IcpBatch
-kw = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+kw = dict(error_threshold=1e-10, max_iterations=int(os.environ.get("MAXIT", "150")), voxel_size=0.04, method="point_to_line", normal_k=12)
 Bs = [int(a) for a in sys.argv[1:]] or [64]
 srcs, tgts = synth.loop_closure_batch(max(Bs), seed0=1000)
 for B in Bs:
