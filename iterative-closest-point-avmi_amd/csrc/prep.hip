@@ -125,8 +125,8 @@ extern "C" int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, 
     int npad = 64;
     while (npad < small_max) npad <<= 1;
     const size_t lds = (size_t)npad * 20 + (size_t)npad * 12;      // lds_points = npad; larger clouds are skipped in-kernel
-    int split = 512 / n_sel;                 // enough workgroups for every CU when the batch is small
-    split = split < 1 ? 1 : (split > 8 ? 8 : split);
+    int split = 256 / n_sel;                 // a workgroup for every CU when the batch is small
+    split = split < 1 ? 1 : (split > 16 ? 16 : split);
 #define ICPMI_PREP_GO(KKV)                                                                                              \
     do {                                                                                                                \
         if (hipFuncSetAttribute((const void*)prep_targets_kernel<KKV>, hipFuncAttributeMaxDynamicSharedMemorySize,      \

@@ -122,9 +122,12 @@ __device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* 
         TopKP<KK> top;
         top.init();
         top.push(0.0, sorig[s], s);
-        // window half-width from the current kk-th best distance (inf until kk neighbours are known);
-        // refreshed only when the list changes
-        double thr = __builtin_inf();
+        // the sweep on one side ends when the gap along the axis alone exceeds the current kk-th best
+        // distance (inf until kk neighbours are known), compared in squares: no sqrt on the path
+        // (gap_exceeds, sweep.hpp: exact on x / y; the diagonals allow for the rounding of x +- y)
+        double bound = __builtin_inf();
+        const double eps = dir < 2 ? 0.0 : 4.5e-16 * (fabs(uq) + uabs);
+        const double widen = dir < 2 ? 1.0 : 2.000000000000002;
         int lo = s - 1, hi = s + 1;
         while (lo >= 0 || hi < M) {
 #pragma unroll
@@ -134,13 +137,14 @@ __device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* 
                     const int i = right ? hi : lo;
                     const double2 c = sxy[i];
                     const double du = right ? proj(dir, c.x, c.y) - uq : uq - proj(dir, c.x, c.y);
-                    if (du > thr) { if (right) hi = M; else lo = -1; }
+                    const double gap = du - eps;
+                    if (gap > 0.0 && gap * gap > bound) { if (right) hi = M; else lo = -1; }
                     else {
                         const double dx = q.x - c.x, dy = q.y - c.y;
                         double d2 = 0.0;
                         d2 += dx * dx;
                         d2 += dy * dy;
-                        if (top.push(d2, sorig[i], i)) thr = prune_width(dir, kk == KK ? top.d[KK - 1] : top.kth(kk - 1), uq, uabs);
+                        if (top.push(d2, sorig[i], i)) bound = (kk == KK ? top.d[KK - 1] : top.kth(kk - 1)) * widen;
                         if (right) ++hi; else --lo;
                     }
                 }
