@@ -59,10 +59,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    # ICPMI_BENCH_REHEARSE=1: every rank on cuda:0 with gloo (collectives staged through the host) — only to
+    # rehearse the multi-rank code path on a one-GPU box; its numbers say nothing about xGMI scaling
+    rehearse = os.environ.get("ICPMI_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if rehearse else dev       # where the scalars of an all_reduce live
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     # ── workload: distinct pairs per rank, inputs resident in HBM before timing ──
     B = args.pairs_per_gpu
@@ -93,7 +102,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
@@ -162,6 +171,10 @@ def main():
             line["raycast"] = bench_raycast(torch, synth, args.raycast_scans, not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(srcs, tgts)
+    if world > 1 and not args.no_raycast:
+        line["map_replay_sharded"] = bench_replay_sharded(torch, dist, synth, args.raycast_scans, rank, world, dev, red_dev)
+    if rehearse:
+        line["data"] = "synthetic (REHEARSAL: all ranks share cuda:0 over gloo; not a scaling measurement)"
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -284,8 +297,8 @@ def bench_submap(torch, synth, with_cpu):
     return res
 
 
-def bench_raycast(torch, synth, n_scans, with_cpu):
-    """BASELINE config 4: 2 242 x 2 402 grid @0.05 m, 2 048-beam scans replayed in order (slam.py:271-277 shape)."""
+def raycast_workload(synth, n_scans):
+    """BASELINE config 4: 2 242 x 2 402 grid @0.05 m, 2 048-beam scans along a short drive -> (grid, origins, hits, cell updates)."""
     from utilities.mapping import OccupancyGrid2D
     p0 = (0.3, -0.2, np.deg2rad(10.0))
     first = synth.to_world(synth.scan(p0, 2), p0)
@@ -300,6 +313,40 @@ def bench_raycast(torch, synth, n_scans, with_cpu):
         ox, oy = np.floor((o[0] - g.min_x) / 0.05), np.floor((o[1] - g.min_y) / 0.05)
         hx, hy = np.floor((h[:, 0] - g.min_x) / 0.05), np.floor((h[:, 1] - g.min_y) / 0.05)
         cells += int(np.maximum(np.abs(hx - ox), np.abs(hy - oy)).sum()) + len(h)
+    return g, org, hits, cells
+
+
+def bench_replay_sharded(torch, dist, synth, n_scans, rank, world, dev, red_dev):
+    """SURVEY §8e map rebuild: every rank replays the whole history into its own band of rows, then one
+    all_gather of the bands.  Band boundaries are planned once (untimed); replay + gather are timed."""
+    from icpmi import dist as idist
+    g, org, hits, cells = raycast_workload(synth, n_scans)
+    d_org = torch.from_numpy(org).to(dev)
+    d_hits = [torch.from_numpy(h).to(dev) for h in hits]
+    bands = idist.row_bands(g.ny, world, idist.row_costs(g.ny, g.min_y, g.resolution, d_org, d_hits))
+    idist.replay_scans_sharded(g, d_org, d_hits, bands=bands)     # warm-up (also of the collective)
+    reps = 5
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.reset()
+        idist.replay_scans_sharded(g, d_org, d_hits, bands=bands)
+    dist.barrier(); torch.cuda.synchronize()
+    dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    checksum = torch.tensor([float(g.device_log_odds.double().sum().item())], dtype=torch.float64, device=red_dev)
+    lo, hi = checksum.clone(), checksum.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return {"workload": f"config 4 grid {g.ny}x{g.nx}, {n_scans} scans x 2048 beams, rows split over {world} GPUs",
+            "bands": bands, "cell_updates": cells, "cells_per_sec": round(cells / dt, 1), "ms_per_replay": round(dt * 1e3, 4),
+            "includes": "grid reset + band replay on every rank + all_gather of the bands",
+            "grids_identical_on_all_ranks": bool(lo.item() == hi.item())}
+
+
+def bench_raycast(torch, synth, n_scans, with_cpu):
+    """BASELINE config 4: 2 048-beam scans replayed in order on one GPU (slam.py:271-277 shape)."""
+    g, org, hits, cells = raycast_workload(synth, n_scans)
     d_org = torch.from_numpy(org).cuda()
     d_hits = torch.from_numpy(np.concatenate(hits)).cuda()
     off = np.zeros(n_scans + 1, dtype=np.int32)

@@ -215,6 +215,21 @@ int icpmi_grid_update_scans(float* log_odds, void* counts, int32_t ny, int32_t n
                             int32_t n_scans, double l_hit, double l_miss, double lo, double hi,
                             int64_t scan_seq, int32_t full_clip, void* stream);
 
+/* The same update restricted to the rows [row_begin, row_end) of the grid: one
+ * rank's band of a sharded map replay (the replay of slam.py:271-277 over a
+ * long history).  Cells are independent and each keeps its scan
+ * order, so replaying every scan on every rank with disjoint bands and then
+ * gathering the bands gives the same grid bit for bit.  log_odds and counts
+ * are FULL-size (ny x nx) buffers; only rows of the band are read or written,
+ * rays are clipped to the band analytically (no steps are walked outside it),
+ * and full_clip clips the band only. */
+int icpmi_grid_update_scans_band(float* log_odds, void* counts, int32_t ny, int32_t nx,
+                                 double min_x, double min_y, double resolution,
+                                 const double* origins, const double* hits, const int32_t* hit_off_host,
+                                 int32_t n_scans, double l_hit, double l_miss, double lo, double hi,
+                                 int64_t scan_seq, int32_t full_clip, int32_t row_begin, int32_t row_end,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

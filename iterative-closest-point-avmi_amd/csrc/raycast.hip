@@ -38,6 +38,7 @@ constexpr int RC_FIN_BLOCKS = ICPMI_RC_FIN_BLOCKS;
 struct GridDesc {
     int nx, ny;
     double min_x, min_y, res;
+    int wy0, wy1;             // rows [wy0, wy1) this call may write (the whole grid, or one rank's band of a sharded replay)
 };
 
 // bounding-box slot: every field grows by atomicMax and 0 means "empty"
@@ -90,10 +91,27 @@ struct Ray {
         const int mj = m0 + sm * k, mn = n0 + sn * q;
         x = xmajor ? mj : mn; y = xmajor ? mn : mj;
     }
-    // steps whose MAJOR coordinate lies inside [0, extent): [klo, khi)
-    __device__ __forceinline__ void clip_major(int extent, int& klo, int& khi) const {
-        if (sm > 0) { klo = max(0, -m0); khi = min(n, extent - m0); }
-        else { klo = max(0, m0 - extent + 1); khi = min(n, m0 + 1); }
+    // steps whose MAJOR coordinate lies inside [lo, hi): [klo, khi)
+    __device__ __forceinline__ void clip_major(int lo, int hi, int& klo, int& khi) const {
+        if (sm > 0) { klo = max(0, lo - m0); khi = min(n, hi - m0); }
+        else { klo = max(0, m0 - hi + 1); khi = min(n, m0 - lo + 1); }
+        if (khi < klo) khi = klo;
+    }
+    // first step whose minor offset is >= qq (n if none): q(k) >= qq  <=>  2*k*dmin + dmaj - 1 >= 2*dmaj*qq
+    __device__ __forceinline__ int first_step_with_offset(long long qq) const {
+        if (qq <= 0) return 0;
+        if (qq > dmin) return n;
+        const long long num = 2ll * dmaj * qq - dmaj + 1, den = 2ll * dmin;       // num > 0, den > 0 (qq <= dmin)
+        const long long k = (num + den - 1) / den;
+        return k > n ? n : (int)k;
+    }
+    // narrow [klo, khi) to the steps whose MINOR coordinate lies inside [lo, hi) (the offset grows with k)
+    __device__ __forceinline__ void clip_minor(int lo, int hi, int& klo, int& khi) const {
+        const long long qa = sn > 0 ? (long long)lo - n0 : (long long)n0 - hi + 1;   // offsets qa .. qb are inside
+        const long long qb = sn > 0 ? (long long)hi - 1 - n0 : (long long)n0 - lo;
+        if (qb < qa) { khi = klo; return; }
+        klo = max(klo, first_step_with_offset(qa));
+        khi = min(khi, first_step_with_offset(qb + 1));
         if (khi < klo) khi = klo;
     }
 };
@@ -121,13 +139,13 @@ __device__ __forceinline__ void ray_count_body(
 
     if (slot == 0) {
         // occupied cell, mapping.py:124-129
-        const bool hit_in = valid && hx >= 0 && hx < g.nx && hy >= 0 && hy < g.ny;
+        const bool hit_in = valid && hx >= 0 && hx < g.nx && hy >= g.wy0 && hy < g.wy1;
         if ((mode & RC_DO_HITS) && hit_in)
             atomicAdd(&counts[(size_t)hy * g.nx + hx], (mode & RC_PACKED) ? 0x10000u : 1u);
         // bounding box of everything this beam can touch: Bresenham stays inside
         // the rectangle spanned by its end points
         int bx0 = max(0, min(ox, hx)), bx1 = min(g.nx - 1, max(ox, hx));
-        int by0 = max(0, min(oy, hy)), by1 = min(g.ny - 1, max(oy, hy));
+        int by0 = max(g.wy0, min(oy, hy)), by1 = min(g.wy1 - 1, max(oy, hy));
         const bool any = valid && bx0 <= bx1 && by0 <= by1;
         uint32_t a = any ? (uint32_t)(g.nx - bx0) : 0u, b = any ? (uint32_t)(g.ny - by0) : 0u;
         uint32_t c = any ? (uint32_t)(bx1 + 1) : 0u, d = any ? (uint32_t)(by1 + 1) : 0u;
@@ -149,12 +167,15 @@ __device__ __forceinline__ void ray_count_body(
     Ray ray;
     ray.init(ox, oy, hx, hy);
     int klo = 0, khi = 0;
-    if (valid) ray.clip_major(ray.xmajor ? g.nx : g.ny, klo, khi);
+    const int minor_lo = ray.xmajor ? g.wy0 : 0, minor_hi = ray.xmajor ? g.wy1 : g.nx;
+    if (valid) {
+        if (ray.xmajor) ray.clip_major(0, g.nx, klo, khi); else ray.clip_major(g.wy0, g.wy1, klo, khi);
+        if (g.wy0 > 0 || g.wy1 < g.ny) ray.clip_minor(minor_lo, minor_hi, klo, khi);   // a band: skip the steps outside it
+    }
     const int len = khi - klo;
     int lmax = len;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) lmax = max(lmax, __shfl_xor(lmax, o, ICPMI_WAVE));
-    const int minor_extent = ray.xmajor ? g.ny : g.nx;
     for (int c0 = slot * RC_STEPS; c0 < lmax; c0 += RC_SLOTS * RC_STEPS) {      // wave-uniform trip count
         const bool live = c0 < len;
         if (live) ray.seek(klo + c0);
@@ -164,7 +185,7 @@ __device__ __forceinline__ void ray_count_body(
             long long cellid = -1;
             if (live && k < khi) {
                 const int mn = ray.n0 + ray.sn * ray.q;
-                if (mn >= 0 && mn < minor_extent) {
+                if (mn >= minor_lo && mn < minor_hi) {
                     int x, y;
                     ray.cell(k, x, y);
                     cellid = (long long)y * g.nx + x;
@@ -236,10 +257,10 @@ __device__ __forceinline__ void ray_finalize_body(const GridDesc& g, const FinAr
     const int count_kind = f.count_kind, clip = f.clip, full_clip = f.full_clip;
     int x0, y0, x1, y1;
     const BBox bb = *bbox;
-    if (full_clip) { x0 = 0; y0 = 0; x1 = g.nx - 1; y1 = g.ny - 1; }
+    if (full_clip) { x0 = 0; y0 = g.wy0; x1 = g.nx - 1; y1 = g.wy1 - 1; }
     else {
         if (bb.inv_x0 == 0) { x0 = 0; y0 = 0; x1 = -1; y1 = -1; }
-        else { x0 = g.nx - (int)bb.inv_x0; y0 = g.ny - (int)bb.inv_y0; x1 = (int)bb.x1p - 1; y1 = (int)bb.y1p - 1; }
+        else { x0 = g.nx - (int)bb.inv_x0; y0 = g.ny - (int)bb.inv_y0; x1 = (int)bb.x1p - 1; y1 = (int)bb.y1p - 1; }   // inside the band by construction
     }
     for (int y = y0 + block; y <= y1; y += nblocks)
         for (int x = x0 + threadIdx.x; x <= x1; x += RC_THREADS) {
@@ -333,14 +354,26 @@ extern "C" int icpmi_grid_update_scans(float* log_odds, void* counts_ws, int32_t
                                        const double* origins, const double* hits, const int32_t* hit_off_host,
                                        int32_t n_scans, double l_hit, double l_miss, double lo, double hi,
                                        int64_t scan_seq, int32_t full_clip, void* stream) {
+    return icpmi_grid_update_scans_band(log_odds, counts_ws, ny, nx, min_x, min_y, resolution, origins, hits, hit_off_host,
+                                        n_scans, l_hit, l_miss, lo, hi, scan_seq, full_clip, 0, ny, stream);
+}
+
+extern "C" int icpmi_grid_update_scans_band(float* log_odds, void* counts_ws, int32_t ny, int32_t nx,
+                                            double min_x, double min_y, double resolution,
+                                            const double* origins, const double* hits, const int32_t* hit_off_host,
+                                            int32_t n_scans, double l_hit, double l_miss, double lo, double hi,
+                                            int64_t scan_seq, int32_t full_clip, int32_t row_begin, int32_t row_end,
+                                            void* stream) {
     using namespace icpmi;
     if (!log_odds || !counts_ws || !origins || !hit_off_host || ny <= 0 || nx <= 0 || n_scans < 0) return ICPMI_ERR_ARG;
+    if (row_begin < 0 || row_end > ny || row_begin > row_end) return ICPMI_ERR_ARG;
+    if (row_begin == row_end) return ICPMI_OK;                  // an empty band: nothing to write
     if (ny > RC_COORD_MAX || nx > RC_COORD_MAX || !(resolution > 0.0)) return ICPMI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const size_t cells = (size_t)ny * (size_t)nx;
     uint32_t* grid2[2] = {(uint32_t*)counts_ws, (uint32_t*)counts_ws + cells};
     BBox* slots = (BBox*)((unsigned char*)counts_ws + 2 * cells * sizeof(uint32_t));
-    GridDesc g{nx, ny, min_x, min_y, resolution};
+    GridDesc g{nx, ny, min_x, min_y, resolution, row_begin, row_end};
     FinArgs fin{};
     fin.log_odds = log_odds; fin.l_hit = l_hit; fin.l_miss = l_miss; fin.lo32 = (float)lo; fin.hi32 = (float)hi;
     bool pending = false;            // a counted scan whose finalisation rides on the next launch

@@ -67,6 +67,10 @@ _SIGS = {
     "icpmi_grid_update_scans": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                           C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
                                           C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_void_p]),
+    "icpmi_grid_update_scans_band": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                               C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
+                                               C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32,
+                                               C.c_int32, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

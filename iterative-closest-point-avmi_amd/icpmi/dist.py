@@ -15,6 +15,17 @@ import torch.distributed as dist
 from . import _lib
 
 
+def _all_gather_into(out, inp, group=None):
+    """all_gather_into_tensor; device tensors under a gloo group (a rehearsal of the multi-rank path on
+    one GPU, or a CPU-only cluster fabric) are staged through host memory, RCCL takes them as they are."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o, i = torch.empty(out.shape, dtype=out.dtype), inp.cpu()
+        dist.all_gather_into_tensor(o, i, group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def shard(n_pairs, rank, world):
     """Indices of the pairs rank ``rank`` owns (interleaved)."""
     return np.arange(rank, n_pairs, world, dtype=np.int64)
@@ -40,7 +51,7 @@ def gather_results(local, n_pairs, rank, world, group=None):
     if world == 1:
         return padded[:n_pairs]
     out = torch.empty((world * per, width), dtype=torch.float64, device=local.device)
-    dist.all_gather_into_tensor(out, padded, group=group)
+    _all_gather_into(out, padded, group)
     # record of pair i sits at rank i % world, slot i // world
     i = torch.arange(n_pairs, device=local.device)
     return out[(i % world) * per + (i // world)]
@@ -89,3 +100,99 @@ def icp_batch_sharded(sources, targets, error_threshold, max_iterations, voxel_s
         b = IcpBatch(clouds, ps, pt, error_threshold, max_iterations, voxel_size, Ri, ti, method, normal_k, max_corr_dist)
         local = b.run()[:k]
     return gather_results(local, n, rank, world, group)
+
+
+# ── sharded map replay: every rank replays all scans into its own band of rows ──────────────
+def _as_tensor(a):
+    return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+
+
+def row_costs(ny, min_y, resolution, origins, hits):
+    """Ray cells per grid row, estimated from the end points only (integer arithmetic, so every rank gets
+    the same numbers): a beam that spans r rows and max(|dx|, |dy|) cells puts cells/r on each of its rows.
+    The x extent is taken in the same units (cells of `resolution`), without the grid's x origin."""
+    sizes = [int(h.shape[0]) for h in hits]
+    if sum(sizes) == 0:
+        return torch.zeros(ny, dtype=torch.int64)
+    h = torch.cat([_as_tensor(x).reshape(-1, 2) for x in hits])
+    dev = h.device
+    org = _as_tensor(origins).reshape(-1, 2).to(dev)
+    o = torch.repeat_interleave(org[: len(sizes)], torch.tensor(sizes, device=dev), dim=0)
+    y0 = torch.floor((o[:, 1] - min_y) / resolution).clamp(-2.0**29, 2.0**29).to(torch.int64)
+    y1 = torch.floor((h[:, 1] - min_y) / resolution).clamp(-2.0**29, 2.0**29).to(torch.int64)
+    dx = torch.floor(torch.abs(h[:, 0] - o[:, 0]) / resolution).clamp(0, 2.0**29).to(torch.int64)
+    lo, hi = torch.minimum(y1, y0), torch.maximum(y1, y0)
+    cells = torch.maximum(hi - lo, dx) + 1
+    w = (cells * 256) // (hi - lo + 1)                           # per-row share, fixed point
+    lo_c, hi_c = lo.clamp(0, ny), (hi + 1).clamp(0, ny)
+    keep = hi_c > lo_c
+    c = torch.zeros(ny + 1, dtype=torch.int64, device=dev)
+    c.index_add_(0, lo_c[keep], w[keep])
+    c.index_add_(0, hi_c[keep], -w[keep])
+    return torch.cumsum(c, 0)[:ny].cpu()
+
+
+def row_bands(ny, world, cost=None):
+    """world + 1 row boundaries 0 = b[0] <= ... <= b[world] = ny; with `cost` (per-row work) the bands carry
+    equal work, otherwise equal rows."""
+    if cost is None or int(cost.sum()) == 0:
+        return [ny * r // world for r in range(world + 1)]
+    cum = torch.cumsum(cost.to(torch.int64), 0)
+    total = int(cum[-1])
+    b = [0]
+    for r in range(1, world):
+        cut = int(torch.searchsorted(cum, torch.tensor((total * r + world - 1) // world, dtype=torch.int64)))
+        b.append(min(ny, max(b[-1], cut + 1)))
+    b.append(ny)
+    return b
+
+
+def gather_bands(band, bands, rank, world, group=None):
+    """all_gather the ranks' bands (rows bands[r]:bands[r+1]) into the full (ny, nx) grid, on band's device."""
+    nx = band.shape[1]
+    ny = bands[-1]
+    if world == 1:
+        return band
+    rows = max(bands[r + 1] - bands[r] for r in range(world))
+    padded = torch.zeros((rows, nx), dtype=band.dtype, device=band.device)
+    padded[: band.shape[0]] = band
+    out = torch.empty((world * rows, nx), dtype=band.dtype, device=band.device)
+    _all_gather_into(out, padded, group)
+    full = torch.empty((ny, nx), dtype=band.dtype, device=band.device)
+    for r in range(world):
+        full[bands[r]:bands[r + 1]] = out[r * rows: r * rows + bands[r + 1] - bands[r]]
+    return full
+
+
+def replay_scans_sharded(grid, origins, hits, group=None, replay=None, balance=True, bands=None):
+    """The map rebuild of slam.py:271-277 (reset + update_scan over the whole history) across the ranks of
+    the process group: rank r replays EVERY scan but writes only rows bands[r]:bands[r+1] of the grid (rays
+    are clipped to the band, so the work is shared too); one all_gather of the bands then gives every rank
+    the complete grid, bit-identical to a single-GPU replay (cells are independent and keep their scan order).
+
+    grid: utilities.mapping.OccupancyGrid2D (same geometry and starting contents on every rank).
+    ``replay(row_begin, row_end) -> (rows, nx) float32 tensor`` replaces the local GPU replay in the CPU tests.
+    bands: row boundaries planned earlier (``row_bands``), e.g. once for many replays of the same history.
+    Returns (row boundaries, the complete grid as a tensor).
+    """
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if bands is None:                  # identical on every rank: integer arithmetic on the same inputs
+        cost = row_costs(grid.ny, grid.min_y, grid.resolution, origins, hits) if balance and world > 1 else None
+        bands = row_bands(grid.ny, world, cost)
+    if len(bands) != world + 1 or bands[0] != 0 or bands[-1] != grid.ny:
+        raise ValueError("bands must hold world + 1 row boundaries from 0 to ny")
+    r0, r1 = bands[rank], bands[rank + 1]
+    if replay is not None:
+        band = replay(r0, r1)
+    else:
+        grid.update_scans(origins, hits, rows=(r0, r1))
+        band = grid.device_log_odds[r0:r1]
+    full = gather_bands(band, bands, rank, world, group)
+    if replay is not None:
+        return bands, full
+    if world > 1:
+        grid.device_log_odds.copy_(full)
+        grid._host = None
+    grid._full_clip = False
+    return bands, grid.device_log_odds

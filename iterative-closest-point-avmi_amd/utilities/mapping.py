@@ -106,11 +106,13 @@ class OccupancyGrid2D:
             raise ValueError("hit_points must have shape (N, 2)")
         self.update_scans(np.asarray(origin_xy, dtype=np.float64).reshape(1, 2), [hit_points])
 
-    def update_scans(self, origins, hits):
+    def update_scans(self, origins, hits, rows=None):
         """Apply several scans in order (the replay of slam.py:271-277) without returning to the host.
 
         origins: (S, 2); hits: list of S arrays (N_s, 2) or one packed (sum N_s, 2)
         torch tensor with ``hit_offsets``-style list semantics.
+        rows=(begin, end): write only that band of grid rows — one rank's share of a sharded
+        replay (``icpmi.dist.replay_scans_sharded``); every other row is left untouched.
         """
         L = _lib.lib()
         S = len(hits)
@@ -128,20 +130,25 @@ class OccupancyGrid2D:
         else:
             host = np.concatenate([np.asarray(h, dtype=np.float64).reshape(-1, 2) for h in hits]) if off[-1] else None
             packed = torch.from_numpy(np.ascontiguousarray(host)).to(self._dev) if host is not None else None
-        self._apply(org, packed, off)
+        self._apply(org, packed, off, rows)
 
-    def _apply(self, org, packed, off):
+    def _apply(self, org, packed, off, rows=None):
         """org (S,2) and packed hits (sum N,2) are float64 device tensors; off is a host int32 array."""
         L = _lib.lib()
         S = len(off) - 1
-        _lib.check(L.icpmi_grid_update_scans(_b._ptr(self._grid), _b._ptr(self._ws), self.ny, self.nx,
-                                             self.min_x, self.min_y, self.resolution, _b._ptr(org), _b._ptr(packed),
-                                             off.ctypes.data_as(C.c_void_p), S, float(self.l_hit), float(self.l_miss),
-                                             self.log_odds_min, self.log_odds_max, self._seq,
-                                             1 if self._full_clip else 0, _b._stream()), "update_scan")
+        r0, r1 = (0, self.ny) if rows is None else (int(rows[0]), int(rows[1]))
+        if not 0 <= r0 <= r1 <= self.ny:
+            raise ValueError("rows must satisfy 0 <= begin <= end <= ny")
+        _lib.check(L.icpmi_grid_update_scans_band(_b._ptr(self._grid), _b._ptr(self._ws), self.ny, self.nx,
+                                                  self.min_x, self.min_y, self.resolution, _b._ptr(org),
+                                                  _b._ptr(packed), off.ctypes.data_as(C.c_void_p), S,
+                                                  float(self.l_hit), float(self.l_miss), self.log_odds_min,
+                                                  self.log_odds_max, self._seq, 1 if self._full_clip else 0,
+                                                  r0, r1, _b._stream()), "update_scan")
         applied = int(np.count_nonzero(np.diff(off)))
-        self._seq += applied
-        if applied:
+        if r1 > r0:
+            self._seq += applied
+        if applied and (r0, r1) == (0, self.ny):
             self._full_clip = False        # every cell is inside [min, max] after a clipped scan
         self._host = None
 

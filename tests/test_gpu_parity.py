@@ -319,6 +319,60 @@ def test_raycast_full_size_properties(umap):
     assert np.array_equal(g.log_odds, ref)
 
 
+def test_band_replay_equals_whole_replay(umap):
+    """every band of rows replayed on its own (as one rank of a sharded replay would) and the
+    bands put together = the unsharded replay = the oracle, bit for bit; rows outside a band stay untouched."""
+    from icpmi import dist as idist, synth
+    rng = np.random.default_rng(21)
+    segs = synth.room_segments()
+    poses = [(0.4 * i - 2.0, 0.25 * i - 1.0, 0.3 * i) for i in range(12)]
+    hits = [synth.to_world(synth.scan(p, 400 + i, segs=segs), p) for i, p in enumerate(poses)]
+    hits[5] = np.empty((0, 2))                                     # an empty scan in the history
+    hits[7] = np.vstack([hits[7], rng.uniform(-40, 40, size=(300, 2))])   # beams that leave the grid
+    org = np.array([[p[0], p[1]] for p in poses])
+    kw = dict(resolution=0.05, p_hit=0.85, p_miss=0.42, log_odds_min=-8.0, log_odds_max=8.0)
+    bounds = (-12.3, 12.1, -8.2, 7.7)
+    ref = None
+    for start_noise in (False, True):
+        whole = umap.OccupancyGrid2D(*bounds, **kw)
+        start = (rng.normal(scale=6.0, size=(whole.ny, whole.nx)).astype(np.float32) if start_noise
+                 else np.zeros((whole.ny, whole.nx), dtype=np.float32))
+        if start_noise:
+            whole.log_odds = start
+        whole.update_scans(org, hits)
+        ref = start.copy()
+        for o, h in zip(org, hits):
+            if len(h):
+                oracle.grid_update_scan(ref, whole.min_x, whole.min_y, 0.05, o, h, whole.l_hit, whole.l_miss, -8.0, 8.0)
+        assert np.array_equal(whole.log_odds, ref)
+        cost = idist.row_costs(whole.ny, whole.min_y, 0.05, org, hits)
+        for bands in (idist.row_bands(whole.ny, 3, cost), idist.row_bands(whole.ny, 8), [0, 1, 2, whole.ny - 1, whole.ny],
+                      [0, 0, whole.ny]):
+            merged = np.full_like(ref, np.nan)
+            for r0, r1 in zip(bands[:-1], bands[1:]):
+                g = umap.OccupancyGrid2D(*bounds, **kw)
+                if start_noise:
+                    g.log_odds = start
+                g.update_scans(org, hits, rows=(r0, r1))
+                lo = g.log_odds
+                outside = np.ones(whole.ny, dtype=bool)
+                outside[r0:r1] = False
+                assert np.array_equal(lo[outside], start[outside]), (bands, r0, r1)   # nothing written outside the band
+                merged[r0:r1] = lo[r0:r1]
+            assert np.array_equal(merged, ref), bands
+    # the sharded entry point with a single rank is the plain replay
+    g = umap.OccupancyGrid2D(*bounds, **kw)
+    bands, full = idist.replay_scans_sharded(g, org, hits)
+    assert bands == [0, g.ny]
+    zero_ref = np.zeros_like(ref)
+    for o, h in zip(org, hits):
+        if len(h):
+            oracle.grid_update_scan(zero_ref, g.min_x, g.min_y, 0.05, o, h, g.l_hit, g.l_miss, -8.0, 8.0)
+    assert np.array_equal(full.cpu().numpy(), zero_ref) and np.array_equal(g.log_odds, zero_ref)
+    with pytest.raises(ValueError):
+        g.update_scans(org, hits, rows=(5, 2))
+
+
 # ── fast (sorted-sweep) path vs exhaustive path ─────────────────────────────
 def test_fast_path_equals_exhaustive_path(uicp):
     """icp2.hip + prep.hip must pick the same correspondences as the exhaustive kernels of icp.hip / normals.hip."""

@@ -130,3 +130,74 @@ def test_sharded_batch_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "GLOO_OK 2" in r.stdout
+
+
+def test_row_bands_cover_and_balance():
+    import torch
+    from icpmi import dist as idist, synth
+    assert idist.row_bands(10, 4) == [0, 2, 5, 7, 10]
+    assert idist.row_bands(7, 1) == [0, 7]
+    segs = synth.room_segments()
+    poses = [(0.0, 0.0, 0.0), (1.0, -0.5, 0.3), (-2.0, 1.0, -0.2)]
+    hits = [synth.to_world(synth.scan(p, 50 + i, segs=segs), p) for i, p in enumerate(poses)]
+    org = np.array([[p[0], p[1]] for p in poses])
+    ny = 800
+    cost = idist.row_costs(ny, -20.0, 0.05, org, hits)
+    assert cost.shape == (ny,) and int(cost.min()) >= 0 and int(cost.sum()) > 0
+    for world in (2, 3, 8):
+        b = idist.row_bands(ny, world, cost)
+        assert b[0] == 0 and b[-1] == ny and all(b[i] <= b[i + 1] for i in range(world))
+        work = [int(cost[b[i]:b[i + 1]].sum()) for i in range(world)]
+        assert max(work) < 1.5 * sum(work) / world, work           # near-equal shares of the estimated work
+    # same numbers from torch tensors as from numpy arrays (every rank must agree)
+    cost_t = idist.row_costs(ny, -20.0, 0.05, torch.from_numpy(org), [torch.from_numpy(h) for h in hits])
+    assert torch.equal(cost, cost_t)
+
+
+REPLAY_WORKER = r"""
+import os, sys, types
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {pkg!r})
+import oracle
+from icpmi import dist as idist, synth
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+segs = synth.room_segments()
+poses = [(0.3 * i, -0.1 * i, 0.05 * i) for i in range(4)]
+hits = [synth.to_world(synth.scan(p, 300 + i, segs=segs), p)[::8] for i, p in enumerate(poses)]
+org = np.array([[p[0], p[1]] for p in poses])
+g = types.SimpleNamespace(ny=300, nx=420, min_x=-10.5, min_y=-7.5, resolution=0.05)
+l_hit, l_miss = float(np.log(0.85 / 0.15)), float(np.log(0.42 / 0.58))
+
+def whole():
+    lo = np.zeros((g.ny, g.nx), dtype=np.float32)
+    for o, h in zip(org, hits):
+        oracle.grid_update_scan(lo, g.min_x, g.min_y, g.resolution, o, h, l_hit, l_miss, -8.0, 8.0)
+    return lo
+
+def replay(r0, r1):          # stand-in for the GPU band replay: cells are independent, so a band is a slice
+    return torch.from_numpy(whole()[r0:r1].copy())
+
+bands, full = idist.replay_scans_sharded(g, org, hits, replay=replay)
+assert len(bands) == world + 1 and bands[0] == 0 and bands[-1] == g.ny
+assert 0 < bands[1] < g.ny                       # both ranks own rows the scans touch
+assert np.array_equal(full.numpy(), whole())
+bands2, full2 = idist.replay_scans_sharded(g, org, hits, replay=replay, balance=False)
+assert bands2 == [0, 150, 300] and np.array_equal(full2.numpy(), whole())
+dist.barrier()
+if rank == 0:
+    print("REPLAY_OK", world, bands)
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_replay_gloo_world2(tmp_path):
+    script = tmp_path / "replay_worker.py"
+    script.write_text(REPLAY_WORKER.format(repo=REPO, pkg=PKG))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29717", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "REPLAY_OK 2" in r.stdout
