@@ -5,16 +5,19 @@ Not a port of the reference's slam.py (its pose graph, display and services are 
 fresh harness with the same per-scan shape (slam.py:377-640) that shows the accelerated path working
 end to end on a synthetic drive:
 
-    scan-to-scan:   rotation_search -> ICP(point_to_line)                 slam.py:53-98, 481-483
+    scan-to-scan:   rotation_search -> ICP(point_to_line), or the IMU     slam.py:53-98, 466-483
+                    yaw step as the initial guess when an IMU log exists
     pose update:    global_pose @ inverse(T)                              slam.py:38-43, 494
-    submap:         RollingSubmap.icp(point_to_point, max_corr_dist)      slam.py:186-225, 505-536
+    submap:         RollingSubmap.attempt_icp: rotation search about the  slam.py:111-225, 505-536
+                    predicted pose (narrow about the IMU yaw) + p2p ICP
     mapping:        OccupancyGrid2D.update_scan                           slam.py:552-557
     loop closure:   batched ICP of the current scan against old scans     slam.py:566-597
 
-It also writes and re-reads the drive in the reference's lidar wire format
-(`timestamp_us;x1;y1;z1;x2;...`, services/lidar_service.py:5-19).
+It also writes and re-reads the drive in the reference's wire formats: lidar lines
+`timestamp_us;x1;y1;z1;x2;...` (services/lidar_service.py:5-19) and IMU lines
+`timestamp_us;qx;qy;qz;qw` (services/imu_service.py:1-38).
 
-    python examples/slam_loop.py [n_scans]
+    python examples/slam_loop.py [n_scans] [--imu]
 """
 import os
 import sys
@@ -53,20 +56,62 @@ def read_lidar_log(path, z_min=0.2, z_max=2.0):
             yield ts, np.ascontiguousarray(p[keep, :2])
 
 
+def write_imu_log(path, yaws, dt_us=100000, per_scan=4, seed=11, noise=0.002):
+    """Orientation quaternions about z, `per_scan` readings per scan interval, yaw noise in radians."""
+    rng = np.random.default_rng(seed)
+    with open(path, "w") as f:
+        for i in range(len(yaws)):
+            nxt = yaws[min(i + 1, len(yaws) - 1)]
+            for j in range(per_scan):
+                yaw = yaws[i] + (nxt - yaws[i]) * j / per_scan + rng.normal(0.0, noise)
+                f.write(f"{1000000 + i * dt_us + j * dt_us // per_scan};0.0;0.0;{float(np.sin(yaw / 2))!r};{float(np.cos(yaw / 2))!r}\n")
+
+
+class ImuLog:
+    """Yaw by timestamp from an orientation log: yaw = atan2(2(qw qz + qx qy), 1 - 2(qy^2 + qz^2)), nearest reading."""
+
+    def __init__(self, path):
+        ts, yaw = [], []
+        with open(path) as f:
+            for line in f:
+                el = line.strip().split(";")
+                if len(el) < 5:
+                    continue
+                qx, qy, qz, qw = (float(v) for v in el[1:5])
+                ts.append(int(el[0]))
+                yaw.append(np.arctan2(2.0 * (qw * qz + qx * qy), 1.0 - 2.0 * (qy * qy + qz * qz)))
+        self.ts, self.yaw = np.array(ts, dtype=np.int64), np.array(yaw)
+
+    def yaw_at(self, t_us):
+        i = int(np.clip(np.searchsorted(self.ts, t_us), 1, len(self.ts) - 1))
+        return self.yaw[i - 1] if t_us - self.ts[i - 1] <= self.ts[i] - t_us else self.yaw[i]
+
+    def delta_yaw(self, t0_us, t1_us):
+        return (self.yaw_at(t1_us) - self.yaw_at(t0_us) + np.pi) % (2 * np.pi) - np.pi
+
+
 def pose_matrix(x, y, th):
     c, s = np.cos(th), np.sin(th)
     return np.array([[c, -s, x], [s, c, y], [0.0, 0.0, 1.0]])
 
 
-def run(n_scans=60, log_path=None, verbose=True):
-    uicp.VERBOSE = features.VERBOSE = False
+def run(n_scans=60, log_path=None, verbose=True, imu_path=None):
+    from icpmi import submap as submap_mod
+    uicp.VERBOSE = features.VERBOSE = submap_mod.VERBOSE = False
     segs = synth.maze_segments()
     truth = synth.trajectory(n_scans, step=0.18)
     scans = [synth.scan(p, 9000 + i, segs=segs) for i, p in enumerate(truth)]
+    stamps = [1000000 + 100000 * i for i in range(n_scans)]
     if log_path:
         write_lidar_log(log_path, scans)
-        scans = [pts for _, pts in read_lidar_log(log_path)]
+        stamps, scans = (list(v) for v in zip(*read_lidar_log(log_path)))
+    imu = None
+    if imu_path:
+        write_imu_log(imu_path, [p[2] for p in truth])
+        imu = ImuLog(imu_path)
+        yaw_offset = imu.yaw_at(stamps[0]) - truth[0][2]          # calibrated so that the first scan has the start yaw
     icp_kw = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+    icp_cfg = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04)
     pose = pose_matrix(*truth[0])                       # start at the true pose; everything after is estimated
     submap = RollingSubmap(window=40, voxel_size=0.04)
     history, mapper, timing = [], None, {"s2s": 0.0, "submap": 0.0, "map": 0.0, "loop": 0.0}
@@ -76,7 +121,13 @@ def run(n_scans=60, log_path=None, verbose=True):
         if prev is not None:
             t0 = time.perf_counter()
             # ICP(prev -> cur) maps the previous scan into the current sensor frame (slam.py:481-483)
-            R0, t0v, _ = features.rotation_search(prev, cur, voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
+            imu_yaw = None
+            if imu is not None:                                               # slam.py:455-479: IMU yaw step as the guess
+                imu_yaw = (imu.yaw_at(stamps[i]) - yaw_offset + np.pi) % (2 * np.pi) - np.pi
+                d = imu.delta_yaw(stamps[i - 1], stamps[i])
+                R0, t0v = np.array([[np.cos(d), np.sin(d)], [-np.sin(d), np.cos(d)]]), np.zeros(2)   # prev -> cur frame
+            else:
+                R0, t0v, _ = features.rotation_search(prev, cur, voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
             r, t, err = uicp.ICP(prev, cur, R_init=R0, t_init=t0v, **icp_kw)
             if err <= 0.15:                                                   # error_reject_threshold, slam.py:485-490
                 T_inv = np.eye(3)
@@ -88,11 +139,10 @@ def run(n_scans=60, log_path=None, verbose=True):
             timing["s2s"] += time.perf_counter() - t0
             t0 = time.perf_counter()
             if len(submap) >= 5:                                              # slam.py:505-536
-                Rs, ts, es, info = submap.icp(cur, 1e-10, 150, 0.04, R_init=pose[:2, :2], t_init=pose[:2, 2],
-                                              method="point_to_point", max_corr_dist=1.5)
+                Rs, ts, es = submap.attempt_icp(cur, pose, imu_yaw, 3.0, 60.0, 0.8, 0.1, 0.2, icp_cfg, 1.5)
                 dpos = np.linalg.norm(ts - pose[:2, 2])
-                dyaw = abs(np.arctan2(Rs[1, 0], Rs[0, 0]) - np.arctan2(pose[1, 0], pose[0, 0]))
-                if np.isfinite(es) and dpos < 1.5 and dyaw < np.deg2rad(15):
+                dyaw = abs((np.arctan2(Rs[1, 0], Rs[0, 0]) - np.arctan2(pose[1, 0], pose[0, 0]) + np.pi) % (2 * np.pi) - np.pi)
+                if es <= 0.15 and dpos < 1.5 and dyaw < np.deg2rad(15):          # slam.py:512-531
                     pose[:2, :2], pose[:2, 2] = Rs, ts
             timing["submap"] += time.perf_counter() - t0
         world = cur @ pose[:2, :2].T + pose[:2, 2]
@@ -128,4 +178,6 @@ def run(n_scans=60, log_path=None, verbose=True):
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, log_path="/tmp/icpmi_demo_lidar.csv")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    run(int(args[0]) if args else 60, log_path="/tmp/icpmi_demo_lidar.csv",
+        imu_path="/tmp/icpmi_demo_imu.csv" if "--imu" in sys.argv else None)

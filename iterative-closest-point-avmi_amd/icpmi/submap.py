@@ -9,11 +9,18 @@ pushed; ``build()`` concatenates them on the device in buffer order and runs the
 voxel filter kernels (bit-identical rows and order to ``np.vstack`` +
 ``voxel_downsample``), and ``icp()`` registers a scan against the result
 without the submap ever visiting the host.
+
+``submap_rotation_search`` / ``attempt_submap_icp`` are the reference's
+``_submap_rotation_search`` / ``_attempt_submap_icp`` (``slam.py:111-225``) on
+the same kernels; both take the submap as a NumPy array or as the device tensor
+``RollingSubmap.build()`` returns.
 """
 import numpy as np
 import torch
 
 from . import batch as _b
+
+VERBOSE = True      # the reference prints a line for corrections above one degree
 
 
 class RollingSubmap:
@@ -91,3 +98,113 @@ class RollingSubmap:
         b.run()
         R, t, err, info = b.unpack()
         return R[0], t[0], err[0], {k: v[0] for k, v in info.items()}
+
+    def rotation_search(self, source_local, predicted_pose, **kw):
+        """submap_rotation_search against the resident submap."""
+        sub, _ = self.build()
+        return submap_rotation_search(source_local, sub, predicted_pose, **kw)
+
+    def attempt_icp(self, source_local, predicted_pose, imu_yaw, imu_narrow, sub_rot_range, sub_rot_step, sub_rot_fine,
+                    sub_rot_voxel, icp_cfg, sub_corr_dist):
+        """attempt_submap_icp against the resident submap (the call of slam.py:505-510)."""
+        sub, _ = self.build()
+        return attempt_submap_icp(source_local, sub, predicted_pose, imu_yaw, imu_narrow, sub_rot_range, sub_rot_step,
+                                  sub_rot_fine, sub_rot_voxel, icp_cfg, sub_corr_dist)
+
+
+# ── slam.py:111-225 ──────────────────────────────────────────────────────────
+def _device_rows(points):
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if isinstance(points, torch.Tensor):
+        t = points.to(dev, torch.float64)
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float64)).to(dev)
+    if t.dim() != 2 or t.shape[1] != 2:
+        raise ValueError("points must have shape (n, 2)")
+    return t.contiguous()
+
+
+def _voxel_rows(points_dev, voxel_size):
+    """voxel_downsample (icp.py:117-129) of a device (n, 2) tensor -> device (m, 2) tensor."""
+    n = points_dev.shape[0]
+    if n == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")   # np.min, icp.py:119
+    out = _b.voxel_downsample_set(_b.CloudSet(points_dev, np.array([0, n], dtype=np.int32)), voxel_size)
+    return out.pts[: int(out.cnt[0].item())]
+
+
+def submap_rotation_search(source_local, submap_global, predicted_pose, angle_range=60.0, angle_step=2.0,
+                           fine_step=0.5, voxel_size=0.3):
+    """slam.py:111-183 -> (R (2,2), t (2,)).
+
+    Sweeps the rotation of the scan about the predicted pose (coarse grid, then a fine grid around the
+    winner; every grid is one kernel launch scoring all its angles), then refines the translation with one
+    nearest-neighbour step over the closest 80 % of the matches.  Angle grids, arg-min, percentile and
+    the mean stay NumPy on the host, on values the kernels produce exactly as the reference's KDTree does.
+    """
+    from utilities.features import rotation_scores
+    _b.require_gpu()
+    predicted_pose = np.asarray(predicted_pose, dtype=np.float64)
+    src_d = _voxel_rows(_device_rows(source_local), voxel_size)               # slam.py:125-126
+    tgt_d = _voxel_rows(_device_rows(submap_global), voxel_size)
+    if len(src_d) < 5 or len(tgt_d) < 5:                                      # slam.py:128-129
+        return predicted_pose[:2, :2], predicted_pose[:2, 2]
+    src = src_d.cpu().numpy()
+    pred_t = predicted_pose[:2, 2]
+    pred_theta = np.arctan2(predicted_pose[1, 0], predicted_pose[0, 0])
+    offsets = np.deg2rad(np.arange(-angle_range, angle_range + angle_step, angle_step))    # slam.py:146-151
+    angles = pred_theta + offsets
+    scores = rotation_scores(src_d, tgt_d, angles, pred_t)
+    best_angle = angles[int(np.argmin(scores))]
+    fine_lo = best_angle - np.deg2rad(angle_step)                             # slam.py:154-159
+    fine_hi = best_angle + np.deg2rad(angle_step)
+    fine_angles = np.arange(fine_lo, fine_hi, np.deg2rad(fine_step))
+    if len(fine_angles) > 0:
+        fine_scores = rotation_scores(src_d, tgt_d, fine_angles, pred_t)
+        best_angle = fine_angles[int(np.argmin(fine_scores))]
+    correction = np.degrees(best_angle - pred_theta)
+    if abs(correction) > 1.0 and VERBOSE:
+        print(f"  Submap rotation correction: {correction:+.1f}°")
+    ca, sa = np.cos(best_angle), np.sin(best_angle)
+    R_best = np.array([[ca, -sa], [sa, ca]])
+    # translation: one nearest-neighbour centroid step, slam.py:168-181
+    rotated_src = src @ R_best.T
+    placed = rotated_src + pred_t
+    both = torch.cat([torch.from_numpy(np.ascontiguousarray(placed)).to(tgt_d.device), tgt_d], dim=0)
+    cs = _b.CloudSet(both, np.array([0, len(placed), len(placed) + len(tgt_d)], dtype=np.int32))
+    dist, idx = _b.nn_set(cs, [0], [1])
+    nn_dists = dist[0, : len(placed)].cpu().numpy()
+    nn_idx = idx[0, : len(placed)].cpu().numpy().astype(np.int64)
+    nn_dists_sq = nn_dists ** 2
+    dist_thresh = np.percentile(nn_dists_sq, 80)
+    inlier_mask = nn_dists_sq <= dist_thresh
+    if inlier_mask.sum() >= 5:
+        matched = tgt_d[torch.from_numpy(nn_idx).to(tgt_d.device)].cpu().numpy()
+        refined_t = np.mean(matched[inlier_mask] - rotated_src[inlier_mask], axis=0)
+    else:
+        refined_t = pred_t
+    return R_best, refined_t
+
+
+def attempt_submap_icp(source, submap, predicted, imu_yaw, imu_narrow, sub_rot_range, sub_rot_step, sub_rot_fine,
+                       sub_rot_voxel, icp_cfg, sub_corr_dist):
+    """slam.py:186-225: rotation search (narrow about the IMU yaw when one is given) + point-to-point ICP
+    against the submap -> (r, t, error) like ``ICP()``."""
+    from utilities import icp as _uicp
+    pred = np.array(predicted, dtype=np.float64, copy=True)
+    if imu_yaw is not None:                                                   # slam.py:200-204
+        ca, sa = np.cos(imu_yaw), np.sin(imu_yaw)
+        pred[:2, :2] = np.array([[ca, -sa], [sa, ca]])
+        angle_range, angle_step = imu_narrow, 0.5
+    else:
+        angle_range, angle_step = sub_rot_range, sub_rot_step
+    R_init, t_init = submap_rotation_search(source, submap, pred, angle_range=angle_range, angle_step=angle_step,
+                                            fine_step=sub_rot_fine, voxel_size=sub_rot_voxel)
+    src_d, sub_d = _device_rows(source), _device_rows(submap)
+    pts = torch.cat([src_d, sub_d], dim=0)
+    cs = _b.CloudSet(pts, np.array([0, len(src_d), len(src_d) + len(sub_d)], dtype=np.int32))
+    b = _b.IcpBatch(cs, [0], [1], icp_cfg.get("error_threshold", 1e-7), icp_cfg.get("max_iterations", 100),
+                    icp_cfg.get("voxel_size", 0.06), R_init, t_init, "point_to_point", 10, sub_corr_dist)
+    b.run()
+    R, t, err, info = b.unpack()
+    return R[0], t[0], _uicp._report(err[0], info, 0, icp_cfg.get("max_iterations", 100))

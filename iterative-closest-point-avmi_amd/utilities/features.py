@@ -26,17 +26,22 @@ def rotation_scores(src_rows, target, angles, shift):
     The scoring function of features.py:213-218 and slam.py:138-143, all angles in one launch."""
     _b.require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device())
-    s = np.ascontiguousarray(src_rows, dtype=np.float64)
-    t = np.ascontiguousarray(target, dtype=np.float64)
+
+    def on_device(x):        # NumPy rows are uploaded; float64 device tensors (a resident submap) are used in place
+        if isinstance(x, torch.Tensor):
+            return x.to(dev, torch.float64).contiguous()
+        return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64)).to(dev)
+
+    d_s, d_t = on_device(src_rows), on_device(target)
     a = np.ascontiguousarray(angles, dtype=np.float64).ravel()
-    if s.ndim != 2 or s.shape[1] != 2 or t.ndim != 2 or t.shape[1] != 2 or len(s) == 0 or len(t) == 0:
+    if d_s.dim() != 2 or d_s.shape[1] != 2 or d_t.dim() != 2 or d_t.shape[1] != 2 or len(d_s) == 0 or len(d_t) == 0:
         raise ValueError("rotation_scores needs non-empty (n, 2) arrays")
     if len(a) == 0:
         return np.empty(0)
     cs = np.ascontiguousarray(np.stack([np.cos(a), np.sin(a)], axis=1))       # features.py:214
-    d_s, d_t, d_cs = (torch.from_numpy(x).to(dev) for x in (s, t, cs))
+    d_cs = torch.from_numpy(cs).to(dev)
     out = torch.empty(len(a), dtype=torch.float64, device=dev)
-    _lib.check(_lib.lib().icpmi_rotation_scores(_b._ptr(d_s), len(s), _b._ptr(d_t), len(t), _b._ptr(d_cs), len(a),
+    _lib.check(_lib.lib().icpmi_rotation_scores(_b._ptr(d_s), len(d_s), _b._ptr(d_t), len(d_t), _b._ptr(d_cs), len(a),
                                                 float(shift[0]), float(shift[1]), _b._ptr(out), _b._stream()),
                "rotation_search")
     return out.cpu().numpy()

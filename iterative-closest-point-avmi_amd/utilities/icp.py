@@ -112,7 +112,6 @@ def ICP(source, target, error_threshold, max_iterations, voxel_size,
     point-to-point, icp.py:162).  R_init is used only together with t_init
     (icp.py:153).  max_corr_dist=None keeps every correspondence.
     """
-    global last_icp_info
     source, target = _as_points(source, "source"), _as_points(target, "target")
     if source.shape[1] != target.shape[1]:
         raise ValueError("source and target differ in dimensionality")
@@ -120,15 +119,21 @@ def ICP(source, target, error_threshold, max_iterations, voxel_size,
         raise ValueError("zero-size array to reduction operation minimum which has no identity")
     R, t, err, info = _b.icp_batch([source], [target], error_threshold, max_iterations, voxel_size,
                                    R_init, t_init, method, normal_k, max_corr_dist)
-    status, iters, delta = int(info["status"][0]), int(info["iters"][0]), float(info["delta"][0])
+    return R[0], t[0], _report(err[0], info, 0, max_iterations)
+
+
+def _report(err, info, i, max_iterations):
+    """The outcome line of icp.py:218,222 for pair i of a batch result; fills ``last_icp_info``; returns the error."""
+    global last_icp_info
+    status, iters, delta = int(info["status"][i]), int(info["iters"][i]), float(info["delta"][i])
     last_icp_info = dict(iterations=iters, status=status, delta=delta)
-    error = float(err[0]) if np.isinf(err[0]) else np.float64(err[0])
+    error = float(err) if np.isinf(err) else np.float64(err)
     if VERBOSE:
         if status == _lib.ST_CONVERGED:
             print(f"  ICP converged: iter={iters - 1}, error={error:.8f}, delta={delta:.2e}")
         else:
             print(f"  ICP max iterations reached: iter={max_iterations}, error={error:.8f}")
-    return R[0], t[0], error
+    return error
 
 
 def run_icp(scan_stream, num_scans=None, error_threshold=1e-5, max_iterations=100, voxel_size=0.5):

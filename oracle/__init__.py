@@ -193,3 +193,42 @@ def rotation_search(source, target, voxel_size=0.3, angle_step_coarse=2.0, angle
     ca, sa = np.cos(fine[i]), np.sin(fine[i])
     R = np.array([[ca, -sa], [sa, ca]])
     return R, mu_t - R @ mu_s, sf[i]
+
+
+def submap_rotation_search(source_local, submap_global, predicted_pose, angle_range=60.0, angle_step=2.0,
+                           fine_step=0.5, voxel_size=0.3):
+    """Restatement of slam.py:111-183 on the oracle's voxel filter, scoring and NN -> (R, t)."""
+    predicted_pose = np.asarray(predicted_pose, dtype=np.float64)
+    src, tgt = voxel_downsample(source_local, voxel_size), voxel_downsample(submap_global, voxel_size)
+    if len(src) < 5 or len(tgt) < 5:
+        return predicted_pose[:2, :2], predicted_pose[:2, 2]
+    pred_t = predicted_pose[:2, 2]
+    pred_theta = np.arctan2(predicted_pose[1, 0], predicted_pose[0, 0])
+    angles = pred_theta + np.deg2rad(np.arange(-angle_range, angle_range + angle_step, angle_step))
+    best = angles[int(np.argmin(rotation_scores(src, tgt, angles, pred_t)))]
+    fine = np.arange(best - np.deg2rad(angle_step), best + np.deg2rad(angle_step), np.deg2rad(fine_step))
+    if len(fine) > 0:
+        best = fine[int(np.argmin(rotation_scores(src, tgt, fine, pred_t)))]
+    ca, sa = np.cos(best), np.sin(best)
+    R = np.array([[ca, -sa], [sa, ca]])
+    rotated = src @ R.T
+    d, idx = nn(rotated + pred_t, tgt)
+    d2 = d ** 2
+    keep = d2 <= np.percentile(d2, 80)
+    t = np.mean(tgt[idx][keep] - rotated[keep], axis=0) if keep.sum() >= 5 else pred_t
+    return R, t
+
+
+def attempt_submap_icp(source, submap, predicted, imu_yaw, imu_narrow, sub_rot_range, sub_rot_step, sub_rot_fine,
+                       sub_rot_voxel, icp_cfg, sub_corr_dist):
+    """Restatement of slam.py:186-225 -> (r, t, error, info)."""
+    pred = np.array(predicted, dtype=np.float64, copy=True)
+    if imu_yaw is not None:
+        ca, sa = np.cos(imu_yaw), np.sin(imu_yaw)
+        pred[:2, :2] = np.array([[ca, -sa], [sa, ca]])
+        rng_, step = imu_narrow, 0.5
+    else:
+        rng_, step = sub_rot_range, sub_rot_step
+    R0, t0 = submap_rotation_search(source, submap, pred, rng_, step, sub_rot_fine, sub_rot_voxel)
+    return icp(source, submap, icp_cfg.get("error_threshold", 1e-7), icp_cfg.get("max_iterations", 100),
+               icp_cfg.get("voxel_size", 0.06), R_init=R0, t_init=t0, method="point_to_point", max_corr_dist=sub_corr_dist)

@@ -326,7 +326,56 @@ def gold_rotation_search():
     save("rotation_search", **out)
 
 
+# ── 10. submap rotation search + scan-to-submap ICP (slam.py:111-225; slam.py imports services/ and utilities/) ──
+def gold_submap_rotation():
+    sys.path.insert(0, REF)
+    ref_slam = _load("ref_slam", os.path.join(REF, "slam.py"))
+    buf, poses, segs = submap_points()
+    submap = ref_icp.voxel_downsample(np.vstack(buf), 0.04)          # == submap_build.npz["out"]
+    x, y, th = poses[-1]
+    true = (x + 0.12 * np.cos(th), y + 0.12 * np.sin(th), th + np.deg2rad(2.0))   # the next pose of the drive
+    src = synth.scan(true, 777, segs=segs)
+
+    def pose(x, y, th):
+        c, s_ = np.cos(th), np.sin(th)
+        return np.array([[c, -s_, x], [s_, c, y], [0.0, 0.0, 1.0]])
+
+    out = {"source": src, "true_pose": pose(*true), "submap_sum": submap.sum(axis=0), "submap_n": np.int64(len(submap))}
+    cases = {
+        "cfg": (pose(true[0] + 0.05, true[1] - 0.04, true[2] + np.deg2rad(7.0)), dict(angle_range=60.0, angle_step=0.8, fine_step=0.1, voxel_size=0.2)),
+        "default": (pose(true[0] - 0.08, true[1] + 0.03, true[2] - np.deg2rad(21.0)), dict()),
+        "imu_narrow": (pose(true[0] + 0.02, true[1] + 0.02, true[2] + np.deg2rad(0.4)), dict(angle_range=3.0, angle_step=0.5, fine_step=0.1, voxel_size=0.2)),
+        "far_off": (pose(true[0] + 0.6, true[1] - 0.5, true[2] + np.deg2rad(50.0)), dict(angle_range=60.0, angle_step=2.0, fine_step=0.5, voxel_size=0.3)),
+    }
+    for k, (pred, kw) in cases.items():
+        buf_ = io.StringIO()
+        with contextlib.redirect_stdout(buf_):
+            R, t = ref_slam._submap_rotation_search(src, submap, pred, **kw)
+        out[f"{k}__pred"], out[f"{k}__R"], out[f"{k}__t"] = pred, R, t
+        out[f"{k}__kw"] = np.array([kw.get("angle_range", 60.0), kw.get("angle_step", 2.0), kw.get("fine_step", 0.5), kw.get("voxel_size", 0.3)])
+        out[f"{k}__printed"] = np.array(buf_.getvalue())
+    # fewer than five points after the filter: the prediction comes back untouched (slam.py:128-129)
+    pred = cases["cfg"][0]
+    R, t = ref_slam._submap_rotation_search(src[:3], submap, pred)
+    out["tiny__R"], out["tiny__t"] = R, t
+    # _attempt_submap_icp (slam.py:186-225) with config.yaml's numbers, without and with an IMU yaw
+    icp_cfg = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04)
+    for k, imu in (("attempt", None), ("attempt_imu", true[2] + np.deg2rad(0.3))):
+        buf_ = io.StringIO()
+        with contextlib.redirect_stdout(buf_):
+            r, t, err = ref_slam._attempt_submap_icp(src, submap, cases["cfg"][0].copy(), imu, 3.0, 60.0, 0.8, 0.1, 0.2, icp_cfg, 1.5)
+        out[f"{k}__R"], out[f"{k}__t"], out[f"{k}__err"] = r, t, np.float64(err)
+        out[f"{k}__imu"] = np.float64(np.nan if imu is None else imu)
+        m = re.search(r"converged: iter=(\d+)", buf_.getvalue())
+        out[f"{k}__iters"] = np.int64(int(m.group(1)) + 1 if m else -1)
+    save("submap_rotation", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                      # python make_golden.py gold_submap_rotation ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     gold_voxel()
     sub = gold_nn()
     gold_normals()
@@ -336,3 +385,4 @@ if __name__ == "__main__":
     gold_grid()
     gold_submap_build()
     gold_rotation_search()
+    gold_submap_rotation()

@@ -42,3 +42,28 @@ def test_slam_loop_tracks_the_drive(tmp_path):
     assert out["drift"].max() < 0.25, out["drift"].max()          # metres, over ~6.5 m driven with 1 cm range noise
     assert out["occupied"] > 1000 and out["free"] > 50000
     assert out["closures"] == [] or all(np.isfinite(c[2]) for c in out["closures"])
+
+
+def test_imu_wire_format_round_trip(tmp_path):
+    """services/imu_service.py:1-38: `timestamp;qx;qy;qz;qw` lines -> yaw about z, nearest reading by timestamp."""
+    m = _load()
+    yaws = [0.0, 0.1, 0.25, -0.4, 3.0, -3.1]
+    path = tmp_path / "imu.csv"
+    m.write_imu_log(str(path), yaws, per_scan=2, noise=0.0)
+    log = m.ImuLog(str(path))
+    assert len(log.ts) == 12 and log.ts[0] == 1000000 and log.ts[2] == 1100000
+    for i, y in enumerate(yaws):
+        assert abs(log.yaw_at(1000000 + 100000 * i) - y) < 1e-12
+    assert abs(log.yaw_at(1000000 + 100000 * 2 + 20000) - 0.25) < 1e-12            # nearest, not interpolated
+    assert abs(log.delta_yaw(1000000 + 400000, 1000000 + 500000) - (2 * np.pi - 6.1)) < 1e-12   # wrapped to (-pi, pi]
+    with open(path, "a") as f:
+        f.write("bad;line\n")
+    assert len(m.ImuLog(str(path)).ts) == 12
+
+
+@pytest.mark.gpu
+def test_slam_loop_with_imu(tmp_path):
+    m = _load()
+    out = m.run(36, log_path=str(tmp_path / "drive.csv"), verbose=False, imu_path=str(tmp_path / "imu.csv"))
+    assert out["drift"].max() < 0.25, out["drift"].max()
+    assert out["occupied"] > 1000 and out["free"] > 50000

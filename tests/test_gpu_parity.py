@@ -569,6 +569,52 @@ def test_rotation_scores_against_oracle(uicp):
         assert int(np.argmin(got)) == int(np.argmin(ref))
 
 
+# ── submap rotation search + scan-to-submap attempt (slam.py:111-225) ──
+@pytest.mark.parametrize("case", ["cfg", "default", "imu_narrow", "far_off"])
+def test_submap_rotation_search_golden(uicp, case, capsys):
+    import torch
+    from icpmi import submap
+    z = load_golden("submap_rotation")
+    sub = load_golden("submap_build")["out"]
+    kw = dict(zip(("angle_range", "angle_step", "fine_step", "voxel_size"), z[f"{case}__kw"]))
+    submap.VERBOSE = True
+    R, t = submap.submap_rotation_search(z["source"], sub, z[f"{case}__pred"], **kw)
+    assert np.array_equal(R, z[f"{case}__R"]) and np.array_equal(t, z[f"{case}__t"])     # bit for bit
+    assert capsys.readouterr().out == str(z[f"{case}__printed"])
+    # the submap as a device tensor (what RollingSubmap.build() hands over) gives the same answer
+    R2, t2 = submap.submap_rotation_search(z["source"], torch.from_numpy(sub).cuda(), z[f"{case}__pred"], **kw)
+    assert np.array_equal(R2, R) and np.array_equal(t2, t)
+
+
+def test_attempt_submap_icp_golden(uicp, capsys):
+    from icpmi import submap, synth
+    z = load_golden("submap_rotation")
+    sub = load_golden("submap_build")["out"]
+    pred = z["cfg__pred"]
+    R, t = submap.submap_rotation_search(z["source"][:3], sub, pred)                      # < 5 points: prediction returned
+    assert np.array_equal(R, z["tiny__R"]) and np.array_equal(t, z["tiny__t"])
+    cfg = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04)
+    uicp.VERBOSE = True
+    for k in ("attempt", "attempt_imu"):
+        imu = None if np.isnan(z[f"{k}__imu"]) else float(z[f"{k}__imu"])
+        before = pred.copy()
+        r, tt, err = submap.attempt_submap_icp(z["source"], sub, pred, imu, 3.0, 60.0, 0.8, 0.1, 0.2, cfg, 1.5)
+        assert np.array_equal(pred, before)                                               # the caller's pose is not modified
+        assert rot_err(r, tt, z[f"{k}__R"], z[f"{k}__t"]) < FRO_TOL
+        assert abs(err - float(z[f"{k}__err"])) < 1e-10
+        assert uicp.last_icp_info["iterations"] == int(z[f"{k}__iters"])
+        assert f"ICP converged: iter={int(z[f'{k}__iters']) - 1}" in capsys.readouterr().out
+    uicp.VERBOSE = False
+    # through the resident rolling submap (slam.py:503-510 shape)
+    segs = synth.maze_segments()
+    poses = synth.trajectory(40)
+    rs = submap.RollingSubmap(window=40, voxel_size=0.04)
+    for i, p in enumerate(poses):
+        rs.push(synth.to_world(synth.scan(p, 500 + i, segs=segs), p))
+    r2, t2, e2 = rs.attempt_icp(z["source"], pred, None, 3.0, 60.0, 0.8, 0.1, 0.2, cfg, 1.5)
+    assert rot_err(r2, t2, z["attempt__R"], z["attempt__t"]) < FRO_TOL and abs(e2 - float(z["attempt__err"])) < 1e-10
+
+
 # ── device-resident rolling submap ──────────────────────
 def test_rolling_submap_equals_build_submap(uicp):
     """slam.py:103-108 + 559-562: 40-scan window, vstack + voxel filter, then scan-to-submap ICP (slam.py:217-225)."""

@@ -206,3 +206,35 @@ def test_rotation_search_matches_reference(case):
     assert np.array_equal(R, z[f"{case}__R"]) and np.array_equal(t, z[f"{case}__t"])
     ref = float(z[f"{case}__score"])
     assert (np.isinf(s) and np.isinf(ref)) or abs(s - ref) < 1e-14
+
+
+def _submap_rotation_inputs():
+    z = load_golden("submap_rotation")
+    sub = load_golden("submap_build")["out"]                 # the 40-scan submap the golden was computed on
+    assert len(sub) == int(z["submap_n"]) and np.array_equal(sub.sum(axis=0), z["submap_sum"])
+    return z, sub
+
+
+@pytest.mark.parametrize("case", ["cfg", "default", "imu_narrow", "far_off"])
+def test_submap_rotation_search_matches_reference(case):
+    """slam.py:111-183: same grids and arg-min -> R bit-equal; the refined translation is a NumPy mean over the
+    same matches -> bit-equal too."""
+    z, sub = _submap_rotation_inputs()
+    kw = z[f"{case}__kw"]
+    R, t = oracle.submap_rotation_search(z["source"], sub, z[f"{case}__pred"], kw[0], kw[1], kw[2], kw[3])
+    assert np.array_equal(R, z[f"{case}__R"])
+    assert np.array_equal(t, z[f"{case}__t"])
+
+
+def test_submap_rotation_search_small_input_and_attempt():
+    z, sub = _submap_rotation_inputs()
+    pred = z["cfg__pred"]
+    R, t = oracle.submap_rotation_search(z["source"][:3], sub, pred)
+    assert np.array_equal(R, z["tiny__R"]) and np.array_equal(t, z["tiny__t"])
+    cfg = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04)
+    for k in ("attempt", "attempt_imu"):
+        imu = None if np.isnan(z[f"{k}__imu"]) else float(z[f"{k}__imu"])
+        r, tt, err, info = oracle.attempt_submap_icp(z["source"], sub, pred, imu, 3.0, 60.0, 0.8, 0.1, 0.2, cfg, 1.5)
+        assert info["iters"] == int(z[f"{k}__iters"])
+        assert np.linalg.norm(r - z[f"{k}__R"]) + np.linalg.norm(tt - z[f"{k}__t"]) < 1e-9
+        assert abs(err - float(z[f"{k}__err"])) < 1e-12
