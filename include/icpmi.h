@@ -230,6 +230,33 @@ int icpmi_grid_update_scans_band(float* log_odds, void* counts, int32_t ny, int3
                                  int64_t scan_seq, int32_t full_clip, int32_t row_begin, int32_t row_end,
                                  void* stream);
 
+/* ── pose graph: PoseGraph2D.optimize, utilities/pose_graph.py:83-134 ──────────
+ * Gauss-Newton on SE(2) over n_nodes poses [x, y, theta] (nodes: device, updated
+ * in place) and n_edges constraints (i, j, z_ij [3], Omega [3][3] row-major).
+ * edges_ij_host: int32 pairs on the HOST (the library classifies the edges and
+ * builds its gather lists from them); edges_z / edges_omega: device.
+ * All iterations run in one launch.  Graphs whose consecutive nodes are all
+ * joined by an edge (the odometry chain slam.py:543-549 builds) are solved as
+ * block-tridiagonal + low-rank; any other graph through the dense 3n x 3n
+ * matrix, as the reference does.  fix_node is held by the 1e10 diagonal of
+ * pose_graph.py:107-112.
+ * info (device, 3 doubles): iterations run, status (0 nothing to do: fewer than
+ * two nodes or no edges; 1 converged: step norm < convergence_eps; 2 iteration
+ * limit; 3 singular system: the nodes keep the values of the previous
+ * iteration, pose_graph.py:117-119), norm of the last step.
+ * workspace: icpmi_pose_graph_workspace_bytes(edges_ij_host, n_nodes, n_edges). */
+size_t icpmi_pose_graph_workspace_bytes(const int32_t* edges_ij_host, int32_t n_nodes, int32_t n_edges);
+int icpmi_pose_graph_optimize(double* nodes, const int32_t* edges_ij_host, const double* edges_z,
+                              const double* edges_omega, int32_t n_nodes, int32_t n_edges,
+                              int32_t n_iterations, int32_t fix_node, double convergence_eps,
+                              double* info, void* workspace, size_t workspace_bytes, void* stream);
+
+/* total_error, pose_graph.py:189-194: sum over edges of e^T Omega e, in edge
+ * order.  Everything on the device; scratch: n_edges doubles; out: 1 double. */
+int icpmi_pose_graph_error(const double* nodes, const int32_t* edges_i, const int32_t* edges_j,
+                           const double* edges_z, const double* edges_omega, int32_t n_edges,
+                           double* scratch, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

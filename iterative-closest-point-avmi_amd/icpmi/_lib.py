@@ -71,6 +71,12 @@ _SIGS = {
                                                C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
                                                C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32,
                                                C.c_int32, C.c_void_p]),
+    "icpmi_pose_graph_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
+    "icpmi_pose_graph_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p]),
+    "icpmi_pose_graph_error": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -32,7 +32,7 @@
 /* voxel_downsample — reference utilities/icp.py:117-129                      */
 /* ------------------------------------------------------------------------- */
 typedef struct { int64_t k[3]; int idx; } vkey_t;
-static int g_vdim;
+static __thread int g_vdim;   /* per thread: the bench times independent pairs on a thread pool */
 static int vkey_cmp(const void* a, const void* b) {
     const vkey_t* x = (const vkey_t*)a; const vkey_t* y = (const vkey_t*)b;
     for (int d = 0; d < g_vdim; ++d) {

@@ -371,6 +371,95 @@ def gold_submap_rotation():
     save("submap_rotation", **out)
 
 
+# ── 11. pose graph (utilities/pose_graph.py: numpy only, loaded by path) ────────────────────────
+def pose_graph_cases():
+    """name -> (nodes (n,3), edges [(i, j, z, omega)], optimize kwargs). Shared with nothing: the tests read the npz."""
+    rng = np.random.default_rng(42)
+
+    def drive(n, loops, noise=0.02, info_scale=(50.0, 400.0), reverse_some=False, full_info=False):
+        th = np.cumsum(rng.normal(0.0, 0.08, n)) + np.linspace(0, 2 * np.pi * 0.9, n)
+        xy = np.cumsum(np.stack([0.4 * np.cos(th), 0.4 * np.sin(th)], axis=1), axis=0)
+        truth = np.column_stack([xy, (th + np.pi) % (2 * np.pi) - np.pi])
+        ref_pg = _load("ref_pg", os.path.join(REF, "utilities", "pose_graph.py"))
+        T = [ref_pg.pose_vec_to_matrix(v) for v in truth]
+        est = [T[0]]
+        edges = []
+        for k in range(1, n):
+            zt = ref_pg.relative_transform_vec(T[k - 1], T[k]) + rng.normal(0.0, noise, 3) * np.array([1, 1, 0.5])
+            est.append(est[-1] @ ref_pg.pose_vec_to_matrix(zt))
+            om = np.eye(3) * rng.uniform(*info_scale)
+            if full_info:
+                q = rng.normal(size=(3, 3))
+                om = q @ q.T + np.eye(3) * 5.0
+            if reverse_some and k % 4 == 0:
+                edges.append((k, k - 1, ref_pg.relative_transform_vec(ref_pg.pose_vec_to_matrix(zt), np.eye(3)), om))
+            else:
+                edges.append((k - 1, k, zt, om))
+        for (a_, b_) in loops:
+            zt = ref_pg.relative_transform_vec(T[a_], T[b_]) + rng.normal(0.0, noise * 0.3, 3)
+            edges.append((a_, b_, zt, np.eye(3) * rng.uniform(500.0, 3000.0)))
+        nodes = np.array([ref_pg.pose_matrix_to_vec(t) for t in est])
+        return nodes, edges
+
+    cases = {}
+    cases["loop30"] = (*drive(30, [(29, 0), (20, 3), (25, 8)]), dict())
+    cases["chain_only"] = (*drive(12, []), dict())
+    n, e = drive(40, [(39, 1), (30, 5)], reverse_some=True, full_info=True)
+    cases["general_info_reversed"] = (n, e, dict(n_iterations=30, fix_node=0))
+    n, e = drive(25, [(24, 2), (12, 0), (24, 2)])
+    cases["anchor_in_the_middle"] = (n, e, dict(fix_node=10, convergence_eps=1e-9))
+    n, e = drive(60, [(59, 0)], noise=0.05)
+    cases["two_iterations_only"] = (n, e, dict(n_iterations=2))
+    n, e = drive(8, [(7, 0)])
+    e[3] = (e[3][0], e[3][1], e[3][2], None)                                   # information=None -> identity
+    cases["information_none"] = (n, e, dict())
+    n, e = drive(10, [])
+    e = [x for k, x in enumerate(e) if k != 4] + [(9, 0, np.zeros(3), np.eye(3))]   # no odometry edge 4-5; the closure keeps it connected
+    cases["gap_in_the_chain"] = (n, e, dict())
+    n, e = drive(6, [])
+    cases["isolated_node_singular"] = (np.vstack([n, [[9.0, 9.0, 0.3]]]), e, dict())    # node 6 has no edge: H is singular
+    cases["no_edges"] = (n, [], dict())
+    cases["one_node"] = (n[:1], [], dict())
+    n, e = drive(300, [(299, 0), (250, 40), (200, 100), (150, 20), (280, 60)], noise=0.01)
+    cases["long300"] = (n, e, dict())
+    return cases
+
+
+def gold_pose_graph():
+    ref_pg = _load("ref_pg", os.path.join(REF, "utilities", "pose_graph.py"))
+    out = {}
+    names = []
+    for name, (nodes, edges, kw) in pose_graph_cases().items():
+        pg = ref_pg.PoseGraph2D()
+        for v in nodes:
+            pg.add_node(v)
+        for (i, j, z, om) in edges:
+            pg.add_edge(i, j, z, om)
+        before = pg.total_error()
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            pg.optimize(**kw)
+        names.append(name)
+        m = len(edges)
+        out[f"{name}__nodes"] = np.asarray(nodes, dtype=np.float64).reshape(-1, 3)
+        out[f"{name}__ij"] = np.array([[i, j] for (i, j, _, _) in edges], dtype=np.int64).reshape(m, 2)
+        out[f"{name}__z"] = np.array([z for (_, _, z, _) in edges], dtype=np.float64).reshape(m, 3)
+        out[f"{name}__omega"] = np.array([np.eye(3) if om is None else om for (_, _, _, om) in edges], dtype=np.float64).reshape(m, 3, 3)
+        out[f"{name}__none"] = np.array([om is None for (_, _, _, om) in edges], dtype=bool)
+        out[f"{name}__kw"] = np.array([kw.get("n_iterations", 20), kw.get("fix_node", 0), kw.get("convergence_eps", 1e-6)], dtype=np.float64)
+        out[f"{name}__out"] = np.array(pg.nodes, dtype=np.float64).reshape(-1, 3)
+        out[f"{name}__err"] = np.array([before, pg.total_error()])
+        out[f"{name}__printed"] = np.array(buf.getvalue())
+        out[f"{name}__mats"] = np.array(pg.get_poses_as_matrices())
+    # helpers, pose_graph.py:15-38
+    a = np.array([-7.0, -np.pi, -1e-17, 0.0, 3.0, np.pi, 9.5, 100.0])
+    out["wrap_in"], out["wrap_out"] = a, ref_pg.normalize_angle(a)
+    T1, T2 = ref_pg.pose_vec_to_matrix([1.0, -2.0, 0.7]), ref_pg.pose_vec_to_matrix([-0.5, 0.25, -2.9])
+    out["T1"], out["T2"] = T1, T2
+    out["rel12"], out["vec1"] = ref_pg.relative_transform_vec(T1, T2), ref_pg.pose_matrix_to_vec(T1)
+    save("pose_graph", names=np.array(names), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # python make_golden.py gold_submap_rotation ...
         for name in sys.argv[1:]:
@@ -386,3 +475,4 @@ if __name__ == "__main__":
     gold_submap_build()
     gold_rotation_search()
     gold_submap_rotation()
+    gold_pose_graph()

@@ -668,3 +668,107 @@ def test_icp_fast_path_shapes(uicp):
                 R, t, err, info = b.unpack()
                 Ro, to, eo, io = oracle.icp(src, tgt, 1e-10, 80, 0.01, **kw)
                 assert rot_err(R[0], t[0], Ro, to) < FRO_TOL and info["iters"][0] == io["iters"], (n_src, n_tgt, method)
+
+
+# ── pose graph (utilities/pose_graph.py) ──────────────────
+def _pose_graph_from_golden(z, name):
+    from utilities import pose_graph as upg
+    pg = upg.PoseGraph2D()
+    for v in z[f"{name}__nodes"]:
+        pg.add_node(v)
+    none = z[f"{name}__none"]
+    for q, ((i, j), zz, om) in enumerate(zip(z[f"{name}__ij"], z[f"{name}__z"], z[f"{name}__omega"])):
+        pg.add_edge(int(i), int(j), zz, None if none[q] else om)
+    kw = z[f"{name}__kw"]
+    return pg, dict(n_iterations=int(kw[0]), fix_node=int(kw[1]), convergence_eps=float(kw[2]))
+
+
+def test_pose_graph_golden(uicp, capsys):
+    """Every case the reference was run on: same outcome line, same poses (to solver rounding), same total error."""
+    import re
+    from utilities import pose_graph as upg
+    z = load_golden("pose_graph")
+    upg.VERBOSE = True
+    for name in z["names"]:
+        pg, kw = _pose_graph_from_golden(z, name)
+        before = pg.total_error()
+        assert abs(before - z[f"{name}__err"][0]) <= 1e-11 * max(1.0, z[f"{name}__err"][0]), name
+        held = [v for v in pg.nodes]
+        pg.optimize(**kw)
+        printed, ref_printed = capsys.readouterr().out, str(z[f"{name}__printed"])
+        strip = lambda s: re.sub(r"\|\|Δx\|\|=.*", "", s)            # the step norm is compared numerically below
+        assert strip(printed) == strip(ref_printed), (name, printed, ref_printed)
+        m = re.search(r"=([0-9.e+-]+)\n", ref_printed) if "Δx" in ref_printed else None
+        if m and float(m.group(1)) > 1e-12:
+            assert abs(pg.last_info["step_norm"] - float(m.group(1))) <= 6e-3 * float(m.group(1)), name
+        out = np.array(pg.nodes).reshape(-1, 3)
+        assert np.abs(out - z[f"{name}__out"]).max() < 1e-8, (name, np.abs(out - z[f"{name}__out"]).max())
+        assert all(a is b for a, b in zip(held, pg.nodes))            # updated in place, like the reference
+        after = pg.total_error()
+        assert abs(after - z[f"{name}__err"][1]) <= 1e-7 * max(1.0, z[f"{name}__err"][1]), name
+        assert np.abs(np.array(pg.get_poses_as_matrices()) - z[f"{name}__mats"]).max() < 1e-8
+    upg.VERBOSE = False
+    assert np.array_equal(upg.normalize_angle(z["wrap_in"]), z["wrap_out"])
+    assert np.array_equal(upg.relative_transform_vec(z["T1"], z["T2"]), z["rel12"])
+    assert np.array_equal(upg.pose_matrix_to_vec(z["T1"]), z["vec1"])
+    assert np.array_equal(upg.pose_vec_to_matrix(z["vec1"]), z["T1"])
+
+
+def test_pose_graph_structured_equals_dense_and_oracle(uicp):
+    """Chain + closures goes through the block-tridiagonal + low-rank solver; the same graph with its nodes
+    renumbered has no chain and goes through the dense solver.  Both must agree with each other and the oracle."""
+    from oracle import pose_graph as opg
+    from utilities import pose_graph as upg
+    rng = np.random.default_rng(7)
+    n = 120
+    th = np.cumsum(rng.normal(0.0, 0.1, n))
+    xy = np.cumsum(np.stack([0.3 * np.cos(th), 0.3 * np.sin(th)], axis=1), axis=0)
+    truth = np.column_stack([xy, upg.normalize_angle(th)])
+    T = [upg.pose_vec_to_matrix(v) for v in truth]
+    est, edges = [T[0]], []
+    for k in range(1, n):
+        zt = upg.relative_transform_vec(T[k - 1], T[k]) + rng.normal(0.0, 0.01, 3)
+        est.append(est[-1] @ upg.pose_vec_to_matrix(zt))
+        edges.append((k - 1, k, zt, np.eye(3) * rng.uniform(100, 1e4)))
+    for a, b in [(119, 0), (100, 7), (90, 30), (60, 60 - 35), (119, 50), (5, 5)]:       # (5, 5): an edge from a node to itself
+        edges.append((a, b, upg.relative_transform_vec(T[a], T[b]) + rng.normal(0.0, 0.003, 3), np.eye(3) * 2e4))
+    nodes = np.array([upg.pose_matrix_to_vec(t) for t in est])
+    perm = rng.permutation(n)                                   # node k of the chain graph is node perm[k] of the shuffled one
+
+    def run(nodes_, edges_, fix):
+        pg = upg.PoseGraph2D()
+        for v in nodes_:
+            pg.add_node(v)
+        for e in edges_:
+            pg.add_edge(*e)
+        pg.optimize(n_iterations=25, fix_node=fix, convergence_eps=1e-9)
+        return np.array(pg.nodes), pg.last_info
+
+    chain, info_c = run(nodes, edges, 3)
+    shuffled_nodes = np.empty_like(nodes)
+    shuffled_nodes[perm] = nodes
+    dense, info_d = run(shuffled_nodes, [(int(perm[i]), int(perm[j]), z_, o) for i, j, z_, o in edges], int(perm[3]))
+    ei, ej = np.array([e[0] for e in edges]), np.array([e[1] for e in edges])
+    zz, om = np.array([e[2] for e in edges]), np.array([e[3] for e in edges])
+    ref, it, st, step = opg.optimize(nodes, ei, ej, zz, om, 25, 3, 1e-9)
+    assert info_c["status"] == info_d["status"] == st == opg.OK and info_c["iterations"] == info_d["iterations"] == it
+    assert np.abs(chain - ref).max() < 1e-8 and np.abs(dense[perm] - ref).max() < 1e-8
+    assert np.abs(chain[3] - nodes[3]).max() < 1e-15            # the anchor stays (its angle is re-wrapped every iteration, as in the reference)
+
+
+def test_pose_graph_edge_cases(uicp, capsys):
+    from utilities import pose_graph as upg
+    pg = upg.PoseGraph2D()
+    pg.optimize()                                               # empty: silent no-op (pose_graph.py:89-91)
+    assert pg.total_error() == 0.0 and pg.add_node([1, 2, 3]) == 0
+    pg.optimize()
+    assert np.array_equal(pg.nodes[0], [1.0, 2.0, 3.0]) and capsys.readouterr().out == ""
+    pg.add_node([2.0, 2.0, 3.0])
+    pg.add_edge(0, 1, [1.0, 0.0, 0.0], np.zeros((3, 3)))        # zero information: H is singular
+    upg.VERBOSE = True
+    pg.optimize()
+    upg.VERBOSE = False
+    assert "singular H at iter 0" in capsys.readouterr().out and np.array_equal(pg.nodes[1], [2.0, 2.0, 3.0])
+    with pytest.raises(IndexError):
+        pg.add_edge(0, 5, [0, 0, 0])
+        pg.optimize()

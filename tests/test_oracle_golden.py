@@ -238,3 +238,40 @@ def test_submap_rotation_search_small_input_and_attempt():
         assert info["iters"] == int(z[f"{k}__iters"])
         assert np.linalg.norm(r - z[f"{k}__R"]) + np.linalg.norm(tt - z[f"{k}__t"]) < 1e-9
         assert abs(err - float(z[f"{k}__err"])) < 1e-12
+
+
+# ── pose graph (utilities/pose_graph.py) ──────────────────
+def pose_graph_case(z, name):
+    ij = z[f"{name}__ij"]
+    kw = z[f"{name}__kw"]
+    return (z[f"{name}__nodes"], ij[:, 0], ij[:, 1], z[f"{name}__z"], z[f"{name}__omega"],
+            dict(n_iterations=int(kw[0]), fix_node=int(kw[1]), convergence_eps=float(kw[2])))
+
+
+def expected_pose_graph_outcome(printed):
+    """(status, iterations run) from the line the reference printed."""
+    import re
+    from oracle import pose_graph as opg
+    m = re.search(r"converged: iter=(\d+)", printed)
+    if m:
+        return opg.OK, int(m.group(1)) + 1
+    m = re.search(r"max iterations: iter=(\d+)", printed)
+    if m:
+        return opg.MAX_ITERATIONS, int(m.group(1))
+    m = re.search(r"singular H at iter (\d+)", printed)
+    if m:
+        return opg.SINGULAR, int(m.group(1))
+    return opg.NOTHING_TO_DO, 0
+
+
+def test_pose_graph_oracle_matches_reference():
+    from oracle import pose_graph as opg
+    z = load_golden("pose_graph")
+    for name in z["names"]:
+        nodes, ei, ej, zz, om, kw = pose_graph_case(z, name)
+        assert abs(opg.total_error(nodes, ei, ej, zz, om) - z[f"{name}__err"][0]) <= 1e-12 * max(1.0, z[f"{name}__err"][0])
+        out, iters, status, step = opg.optimize(nodes, ei, ej, zz, om, **kw)
+        assert (status, iters) == expected_pose_graph_outcome(str(z[f"{name}__printed"])), name
+        assert np.abs(out - z[f"{name}__out"]).max() < 1e-10, (name, np.abs(out - z[f"{name}__out"]).max())
+        assert abs(opg.total_error(out, ei, ej, zz, om) - z[f"{name}__err"][1]) <= 1e-9 * max(1.0, z[f"{name}__err"][1])
+    assert np.array_equal(opg.wrap(z["wrap_in"]), z["wrap_out"])
