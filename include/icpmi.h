@@ -240,10 +240,12 @@ int icpmi_grid_update_scans_band(float* log_odds, void* counts, int32_t ny, int3
  * block-tridiagonal + low-rank; any other graph through the dense 3n x 3n
  * matrix, as the reference does.  fix_node is held by the 1e10 diagonal of
  * pose_graph.py:107-112.
- * info (device, 3 doubles): iterations run, status (0 nothing to do: fewer than
- * two nodes or no edges; 1 converged: step norm < convergence_eps; 2 iteration
- * limit; 3 singular system: the nodes keep the values of the previous
- * iteration, pose_graph.py:117-119), norm of the last step.
+ * info (device, 10 doubles): iterations run, status (0 nothing to do: fewer
+ * than two nodes or no edges; 1 converged: step norm < convergence_eps; 2
+ * iteration limit; 3 singular system: the nodes keep the values of the previous
+ * iteration, pose_graph.py:117-119), norm of the last step; then the time spent
+ * per phase in microseconds, summed over the iterations (assembly, chain
+ * factorisation, chain sweeps, closure system, its solve, update of dx, apply).
  * workspace: icpmi_pose_graph_workspace_bytes(edges_ij_host, n_nodes, n_edges). */
 size_t icpmi_pose_graph_workspace_bytes(const int32_t* edges_ij_host, int32_t n_nodes, int32_t n_edges);
 int icpmi_pose_graph_optimize(double* nodes, const int32_t* edges_ij_host, const double* edges_z,

@@ -7,9 +7,9 @@
 //     H = T + W C W^T
 // with T block tridiagonal (3x3 blocks: the chain edges and the anchor), W the
 // 3n x 3k Jacobian columns of the k other edges and C = blockdiag(Omega_e):
-//     T^-1 by block LU along the chain (all 1 + 3k right-hand sides at once, one
-//     thread per column), then the 3k x 3k system (I + C W^T T^-1 W) y = C W^T T^-1 r,
-//     dx = T^-1 r - T^-1 W y.
+//     T^-1 by block cyclic reduction along the chain (log2 n levels, each parallel
+//     over nodes and over all 1 + 3k right-hand sides), then the 3k x 3k system
+//     (I + C W^T T^-1 W) y = C W^T T^-1 r,  dx = T^-1 r - T^-1 W y.
 // O(n k^2) work instead of O(n^3), and the whole optimisation — every
 // iteration's linearisation, solve, update and convergence test — runs inside
 // ONE persistent workgroup: no launches or host round trips between iterations.
@@ -24,7 +24,7 @@
 
 namespace icpmi {
 
-constexpr int PG_THREADS = 1024;
+constexpr int PG_THREADS = 512;                    // one workgroup, 2 waves per SIMD
 constexpr double PG_PI = 3.141592653589793;        // np.pi
 constexpr double PG_2PI = 6.283185307179586;       // 2 * np.pi
 
@@ -40,8 +40,8 @@ struct PgArgs {
     const int32_t* loop_edge;      // [k] edge ids of the non-chain edges
     int n, m, k, dense, n_iter, fix;
     double eps;
-    double *D, *U, *L, *b;         // block tridiagonal T: D[v] = H[v][v], U[v] = H[v][v+1], L[v] = H[v+1][v]
-    double *Dinv, *G;              // inverse of the eliminated diagonal block, G[v] = L[v-1] * Dinv[v-1]
+    double *D, *U, *L, *b;         // block tridiagonal T per node: D[v] = H[v][v], U[v] = H[v][v+s], L[v] = H[v][v-s] (s = level stride)
+    double *Dinv, *G;              // per even node of a level: L[e] * inv(D[e-s]) and U[e] * inv(D[e+s])
     double* X;                     // [3n][1 + 3k] right-hand sides -> solutions (column 0 = r = -b, then W)
     double* AB;                    // [k][18] Jacobians of the non-chain edges
     double *M, *g, *y;             // [3k][3k], [3k], [3k]
@@ -151,33 +151,44 @@ __device__ __forceinline__ double block_total(double v, double* s_val) {
 // "singular matrix", the LinAlgError of pose_graph.py:117-119).
 __device__ bool block_lu_solve(double* a, int N, double* rhs, double* s_val, int* s_idx) {
     const int tid = threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;                       // update tile: 32 columns x (PG_THREADS / 32) rows
     for (int p = 0; p < N; ++p) {
-        double best = -1.0; int bi = 0x7fffffff;
-        for (int r = p + tid; r < N; r += PG_THREADS) {
-            const double v = fabs(a[(size_t)r * N + p]);
-            if (v > best) { best = v; bi = r; }
+        if (wave_id() == 0) {                                     // pivot search: one wave, no workgroup barriers
+            double best = -1.0; int bi = 0x7fffffff;
+            for (int r = p + lane_id(); r < N; r += ICPMI_WAVE) {
+                const double v = fabs(a[(size_t)r * N + p]);
+                if (v > best) { best = v; bi = r; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o, ICPMI_WAVE);
+                const int oi = __shfl_xor(bi, o, ICPMI_WAVE);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane_id() == 0) { s_val[0] = best; s_idx[0] = bi; }
         }
-        double pv; int pr;
-        block_argmax(best, bi, s_val, s_idx, pv, pr);
+        __syncthreads();
+        const double pv = s_val[0];
+        const int pr = s_idx[0];
         if (!(pv > 0.0)) return false;
         if (pr != p) {
-            for (int c = tid; c < N; c += PG_THREADS) {
+            for (int c = p + tid; c < N; c += PG_THREADS) {       // columns left of p are never read again
                 const double t = a[(size_t)p * N + c];
                 a[(size_t)p * N + c] = a[(size_t)pr * N + c];
                 a[(size_t)pr * N + c] = t;
             }
             if (tid == 0) { const double t = rhs[p]; rhs[p] = rhs[pr]; rhs[pr] = t; }
-            __syncthreads();
         }
-        const double piv = a[(size_t)p * N + p];
-        for (int r = p + 1 + tid; r < N; r += PG_THREADS) a[(size_t)r * N + p] /= piv;     // multipliers
         __syncthreads();
-        const int rows = N - p - 1, cols = N - p;                                          // trailing block + rhs column
-        for (long long t = tid; t < (long long)rows * cols; t += PG_THREADS) {
-            const int r = p + 1 + (int)(t / cols), cc = (int)(t % cols);
-            const double l = a[(size_t)r * N + p];
-            if (cc == cols - 1) rhs[r] -= l * rhs[p];
-            else a[(size_t)r * N + p + 1 + cc] -= l * a[(size_t)p * N + p + 1 + cc];
+        // eliminate column p from the rows below; column p itself is only read here, so every thread takes its
+        // row's multiplier from it directly (column index N stands for the right-hand side)
+        const double piv = a[(size_t)p * N + p];
+        for (int r = p + 1 + ty; r < N; r += PG_THREADS / 32) {
+            const double l = a[(size_t)r * N + p] / piv;
+            for (int c = p + 1 + tx; c <= N; c += 32) {
+                if (c == N) rhs[r] -= l * rhs[p];
+                else a[(size_t)r * N + c] -= l * a[(size_t)p * N + c];
+            }
         }
         __syncthreads();
     }
@@ -199,6 +210,12 @@ __global__ __launch_bounds__(PG_THREADS) void pose_graph_kernel(PgArgs g) {
     const int n = g.n, k = g.k, K = 3 * g.k, ncols = 1 + 3 * g.k, N3 = 3 * g.n, f = g.fix;
     int status = PG_MAXITER, iters = g.n_iter;
     double step = 0.0;
+    // phase clocks (thread 0, 100 MHz wall clock): assemble, chain LU + W, sweeps, closure system, its solve, dx, update
+    long long t_acc[7] = {0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
+#define PG_MARK(i)                                                                      \
+    do {                                                                                \
+        if (tid == 0) { const long long now = wall_clock64(); t_acc[i] += now - t_last; t_last = now; } \
+    } while (0)
 
     for (int it = 0; it < g.n_iter; ++it) {
         if (tid == 0) s_flag = 0;
@@ -252,33 +269,20 @@ __global__ __launch_bounds__(PG_THREADS) void pose_graph_kernel(PgArgs g) {
                 else for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) g.Hd[(size_t)(3 * v + r) * N3 + 3 * v + cc] += D.a[3 * r + cc];
                 for (int c = 0; c < 3; ++c) g.dx[3 * v + c] = -b[c];
             } else {
-                m3_store(g.D + 9 * (size_t)v, D); m3_store(g.U + 9 * (size_t)v, U); m3_store(g.L + 9 * (size_t)v, L);
+                // per node: D[v] = H[v][v], U[v] = H[v][v+1] (zero for the last node), L[v] = H[v][v-1] (zero for node 0)
+                m3_store(g.D + 9 * (size_t)v, D); m3_store(g.U + 9 * (size_t)v, U);
+                if (v + 1 < n) m3_store(g.L + 9 * (size_t)(v + 1), L);
+                if (v == 0) m3_store(g.L, m3_zero());
                 for (int c = 0; c < 3; ++c) g.X[(size_t)(3 * v + c) * ncols] = -b[c];           // column 0: r = -b
             }
         }
         __syncthreads();
+        PG_MARK(0);
 
         bool singular = false;
         if (g.dense) {
             singular = !block_lu_solve(g.Hd, N3, g.dx, s_val, s_idx);
         } else {
-            // ── block LU of T along the chain (sequential in v, one thread) ──────────
-            if (tid == 0) {
-                M3 prev_inv = m3_zero();
-                bool ok = true;
-                for (int v = 0; v < n && ok; ++v) {
-                    M3 Dp = m3_load(g.D + 9 * (size_t)v);
-                    M3 G = m3_zero();
-                    if (v > 0) {
-                        G = m3_mul(m3_load(g.L + 9 * (size_t)(v - 1)), prev_inv);
-                        m3_sub(Dp, m3_mul(G, m3_load(g.U + 9 * (size_t)(v - 1))));
-                    }
-                    m3_store(g.G + 9 * (size_t)v, G);
-                    ok = m3_inv(Dp, prev_inv);
-                    m3_store(g.Dinv + 9 * (size_t)v, prev_inv);
-                }
-                if (!ok) s_flag = 1;
-            }
             // ── right-hand sides 1..3k: the Jacobian columns W of the non-chain edges ──
             for (size_t t = tid; t < (size_t)N3 * (size_t)K; t += PG_THREADS) g.X[(t / K) * ncols + 1 + (t % K)] = 0.0;
             __syncthreads();
@@ -296,29 +300,83 @@ __global__ __launch_bounds__(PG_THREADS) void pose_graph_kernel(PgArgs g) {
                     }
             }
             __syncthreads();
-            singular = s_flag != 0;
-            if (!singular) {
-                // ── T^-1 on every column: forward then backward sweep, one thread per column ──
-                for (int col = tid; col < ncols; col += PG_THREADS) {
-                    double zp[3] = {0.0, 0.0, 0.0};
-                    for (int v = 0; v < n; ++v) {
-                        double x[3], t3[3];
-                        for (int c = 0; c < 3; ++c) x[c] = g.X[(size_t)(3 * v + c) * ncols + col];
-                        const M3 G = m3_load(g.G + 9 * (size_t)v);
-                        m3_vec(G, zp, t3);
-                        for (int c = 0; c < 3; ++c) { zp[c] = x[c] - t3[c]; g.X[(size_t)(3 * v + c) * ncols + col] = zp[c]; }
-                    }
-                    double yn[3] = {0.0, 0.0, 0.0};
-                    for (int v = n - 1; v >= 0; --v) {
-                        double x[3], t3[3], w[3];
-                        for (int c = 0; c < 3; ++c) x[c] = g.X[(size_t)(3 * v + c) * ncols + col];
-                        m3_vec(m3_load(g.U + 9 * (size_t)v), yn, t3);                           // U[n-1] is zero
-                        for (int c = 0; c < 3; ++c) w[c] = x[c] - t3[c];
-                        m3_vec(m3_load(g.Dinv + 9 * (size_t)v), w, yn);
-                        for (int c = 0; c < 3; ++c) g.X[(size_t)(3 * v + c) * ncols + col] = yn[c];
-                    }
+            PG_MARK(1);
+            // ── T^-1 on every column by block cyclic reduction along the chain ───────
+            // Level with stride s: the nodes that are odd multiples of s are eliminated into their neighbours at
+            // distance s (which then couple at distance 2s); log2(n) levels, every level parallel over nodes and
+            // columns.  An eliminated node keeps its inverted diagonal block and its two couplings for the way back.
+            int s = 1;
+            for (; s < n; s <<= 1) {
+                for (int idx = tid; s * (2 * idx + 1) < n; idx += PG_THREADS) {          // odd nodes: invert the diagonal block
+                    const int i = s * (2 * idx + 1);
+                    M3 inv;
+                    if (!m3_inv(m3_load(g.D + 9 * (size_t)i), inv)) s_flag = 1;
+                    m3_store(g.D + 9 * (size_t)i, inv);
                 }
                 __syncthreads();
+                for (int idx = tid; 2 * s * idx < n; idx += PG_THREADS) {                // even nodes: absorb both odd neighbours
+                    const int e = 2 * s * idx, i1 = e - s, i2 = e + s;
+                    M3 P = m3_zero(), Q = m3_zero(), Dn = m3_load(g.D + 9 * (size_t)e), Ln = m3_zero(), Un = m3_zero();
+                    if (i1 >= 0) {
+                        P = m3_mul(m3_load(g.L + 9 * (size_t)e), m3_load(g.D + 9 * (size_t)i1));
+                        m3_sub(Dn, m3_mul(P, m3_load(g.U + 9 * (size_t)i1)));
+                        Ln = m3_mul(P, m3_load(g.L + 9 * (size_t)i1));
+                        for (int c = 0; c < 9; ++c) Ln.a[c] = -Ln.a[c];
+                    }
+                    if (i2 < n) {
+                        Q = m3_mul(m3_load(g.U + 9 * (size_t)e), m3_load(g.D + 9 * (size_t)i2));
+                        m3_sub(Dn, m3_mul(Q, m3_load(g.L + 9 * (size_t)i2)));
+                        Un = m3_mul(Q, m3_load(g.U + 9 * (size_t)i2));
+                        for (int c = 0; c < 9; ++c) Un.a[c] = -Un.a[c];
+                    }
+                    m3_store(g.Dinv + 9 * (size_t)e, P); m3_store(g.G + 9 * (size_t)e, Q);
+                    m3_store(g.D + 9 * (size_t)e, Dn); m3_store(g.L + 9 * (size_t)e, Ln); m3_store(g.U + 9 * (size_t)e, Un);
+                }
+                __syncthreads();
+                const int n_even = (n + 2 * s - 1) / (2 * s);
+                for (int t = tid; t < n_even * ncols; t += PG_THREADS) {                 // right-hand sides of the even nodes
+                    const int e = 2 * s * (t / ncols), col = t % ncols, i1 = e - s, i2 = e + s;
+                    double r[3], x1[3] = {0.0, 0.0, 0.0}, x2[3] = {0.0, 0.0, 0.0}, t1[3], t2[3];
+                    for (int c = 0; c < 3; ++c) r[c] = g.X[(size_t)(3 * e + c) * ncols + col];
+                    if (i1 >= 0) for (int c = 0; c < 3; ++c) x1[c] = g.X[(size_t)(3 * i1 + c) * ncols + col];
+                    if (i2 < n) for (int c = 0; c < 3; ++c) x2[c] = g.X[(size_t)(3 * i2 + c) * ncols + col];
+                    m3_vec(m3_load(g.Dinv + 9 * (size_t)e), x1, t1);
+                    m3_vec(m3_load(g.G + 9 * (size_t)e), x2, t2);
+                    for (int c = 0; c < 3; ++c) g.X[(size_t)(3 * e + c) * ncols + col] = (r[c] - t1[c]) - t2[c];
+                }
+                __syncthreads();
+            }
+            if (tid == 0) {                                                              // the last node standing: node 0
+                M3 inv;
+                if (!m3_inv(m3_load(g.D), inv)) s_flag = 1;
+                m3_store(g.D, inv);
+            }
+            __syncthreads();
+            singular = s_flag != 0;
+            if (!singular) {
+                for (int col = tid; col < ncols; col += PG_THREADS) {
+                    double r[3], x[3];
+                    for (int c = 0; c < 3; ++c) r[c] = g.X[(size_t)c * ncols + col];
+                    m3_vec(m3_load(g.D), r, x);
+                    for (int c = 0; c < 3; ++c) g.X[(size_t)c * ncols + col] = x[c];
+                }
+                __syncthreads();
+                for (s >>= 1; s >= 1; s >>= 1) {                                         // back: the odd nodes of every level
+                    const int n_odd = (n - s + 2 * s - 1) / (2 * s);                     // nodes s, 3s, 5s, ... below n
+                    for (int t = tid; t < n_odd * ncols; t += PG_THREADS) {
+                        const int i = s * (2 * (t / ncols) + 1), col = t % ncols, a = i - s, b = i + s;
+                        double r[3], xa[3], xb[3] = {0.0, 0.0, 0.0}, t1[3], t2[3], w[3], x[3];
+                        for (int c = 0; c < 3; ++c) { r[c] = g.X[(size_t)(3 * i + c) * ncols + col]; xa[c] = g.X[(size_t)(3 * a + c) * ncols + col]; }
+                        if (b < n) for (int c = 0; c < 3; ++c) xb[c] = g.X[(size_t)(3 * b + c) * ncols + col];
+                        m3_vec(m3_load(g.L + 9 * (size_t)i), xa, t1);
+                        m3_vec(m3_load(g.U + 9 * (size_t)i), xb, t2);
+                        for (int c = 0; c < 3; ++c) w[c] = (r[c] - t1[c]) - t2[c];
+                        m3_vec(m3_load(g.D + 9 * (size_t)i), w, x);
+                        for (int c = 0; c < 3; ++c) g.X[(size_t)(3 * i + c) * ncols + col] = x[c];
+                    }
+                    __syncthreads();
+                }
+                PG_MARK(2);
                 if (k > 0) {
                     // ── (I + C W^T Y) y = C W^T T^-1 r ───────────────────────────────────
                     for (int t = tid; t < K * (K + 1); t += PG_THREADS) {
@@ -342,18 +400,25 @@ __global__ __launch_bounds__(PG_THREADS) void pose_graph_kernel(PgArgs g) {
                         else g.M[(size_t)r * K + c] = acc + (r == c ? 1.0 : 0.0);
                     }
                     __syncthreads();
+                    PG_MARK(3);
                     singular = !block_lu_solve(g.M, K, g.g, s_val, s_idx);
+                    PG_MARK(4);
                 }
                 if (!singular) {
-                    for (int t = tid; t < N3; t += PG_THREADS) {
-                        double d = g.X[(size_t)t * ncols];
-                        for (int c = 0; c < K; ++c) d -= g.X[(size_t)t * ncols + 1 + c] * g.g[c];
-                        g.dx[t] = d;
+                    // dx = Y[:, 0] - Y[:, 1:] y: one wave per row, lanes along the row (coalesced), fixed-tree sum
+                    const int l16 = tid & 15;
+                    for (int t0 = 0; t0 < N3; t0 += PG_THREADS / 16) {                   // 16 lanes per row, uniform trip count
+                        const int t = min(t0 + (tid >> 4), N3 - 1);
+                        double part = 0.0;
+                        for (int c = l16; c < K; c += 16) part += g.X[(size_t)t * ncols + 1 + c] * g.g[c];
+                        const double tot = row_sum(part);
+                        if (l16 == 0 && t0 + (tid >> 4) < N3) g.dx[t] = g.X[(size_t)t * ncols] - tot;
                     }
                 }
             }
         }
         __syncthreads();
+        PG_MARK(5);
         if (singular) { status = PG_SINGULAR; iters = it; break; }           // pose_graph.py:117-119: nodes keep their values
         // ── apply the update, pose_graph.py:121-129 ──────────────────────────────
         double ss = 0.0;
@@ -365,9 +430,14 @@ __global__ __launch_bounds__(PG_THREADS) void pose_graph_kernel(PgArgs g) {
             ss += (d0 * d0 + d1 * d1) + d2 * d2;
         }
         step = sqrt(block_total(ss, s_val));
+        PG_MARK(6);
         if (step < g.eps) { status = PG_CONVERGED; iters = it + 1; break; }
     }
-    if (tid == 0) { g.info[0] = (double)iters; g.info[1] = (double)status; g.info[2] = step; }
+    if (tid == 0) {
+        g.info[0] = (double)iters; g.info[1] = (double)status; g.info[2] = step;
+        for (int i = 0; i < 7; ++i) g.info[3 + i] = (double)t_acc[i] * 0.01;      // microseconds per phase, all iterations
+    }
+#undef PG_MARK
 }
 
 // total_error, pose_graph.py:189-194: e^T Omega e summed in edge order
@@ -455,7 +525,7 @@ extern "C" int icpmi_pose_graph_optimize(double* nodes, const int32_t* edges_ij_
     if (n_edges > 0 && (!edges_ij_host || !edges_z || !edges_omega)) return ICPMI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (n_nodes < 2 || n_edges == 0 || n_iterations == 0) {                  // pose_graph.py:89-91: nothing to do
-        const double none[3] = {0.0, n_iterations == 0 && n_nodes >= 2 && n_edges > 0 ? (double)PG_MAXITER : (double)PG_NOTHING, 0.0};
+        const double none[10] = {0.0, n_iterations == 0 && n_nodes >= 2 && n_edges > 0 ? (double)PG_MAXITER : (double)PG_NOTHING, 0.0};
         if (hipMemcpyAsync(info, none, sizeof(none), hipMemcpyHostToDevice, st) != hipSuccess) return ICPMI_ERR_HIP;
         if (hipStreamSynchronize(st) != hipSuccess) return ICPMI_ERR_HIP;    // `none` is on this stack frame
         return ICPMI_OK;

@@ -94,7 +94,7 @@ class PoseGraph2D:
         fix = fix_node + n if fix_node < 0 else fix_node
         d_nodes = torch.from_numpy(np.ascontiguousarray(np.array(self.nodes, dtype=np.float64).reshape(n, 3))).to(dev)
         d_z, d_om = torch.from_numpy(z).to(dev), torch.from_numpy(om).to(dev)
-        info = torch.zeros(3, dtype=torch.float64, device=dev)
+        info = torch.zeros(10, dtype=torch.float64, device=dev)
         ijp = ij.ctypes.data_as(C.c_void_p)
         need = L.icpmi_pose_graph_workspace_bytes(ijp, n, m)
         ws = torch.empty(max(int(need), 256), dtype=torch.uint8, device=dev)
@@ -102,11 +102,13 @@ class PoseGraph2D:
                                                int(n_iterations), int(fix), float(convergence_eps), _b._ptr(info),
                                                _b._ptr(ws), ws.numel(), _b._stream()), "PoseGraph2D.optimize")
         out = d_nodes.cpu().numpy()
-        iters, status, step = info.cpu().numpy()
-        iters, status = int(iters), int(status)
+        info = info.cpu().numpy()
+        iters, status, step = int(info[0]), int(info[1]), info[2]
         for k in range(n):                                   # in place, like pose_graph.py:122-125
             self.nodes[k][:] = out[k]
-        self.last_info = dict(iterations=iters, status=status, step_norm=float(step))
+        self.last_info = dict(iterations=iters, status=status, step_norm=float(step),
+                              phase_us=dict(zip(("assemble", "chain_lu", "chain_sweeps", "closure_system",
+                                                 "closure_solve", "dx", "apply"), info[3:10].tolist())))
         if VERBOSE:
             if status == SINGULAR:
                 print(f"  PoseGraph: singular H at iter {iters}, stopping")
