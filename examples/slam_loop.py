@@ -11,13 +11,16 @@ end to end on a synthetic drive:
     submap:         RollingSubmap.attempt_icp: rotation search about the  slam.py:111-225, 505-536
                     predicted pose (narrow about the IMU yaw) + p2p ICP
     mapping:        OccupancyGrid2D.update_scan                           slam.py:552-557
-    loop closure:   batched ICP of the current scan against old scans     slam.py:566-597
+    loop closure:   batched ICP of the current scan against old scans;    slam.py:566-620
+                    an accepted closure adds a pose-graph edge, the graph
+                    is optimised, poses are rewritten, the submap buffer
+                    and the occupancy grid are rebuilt (replay of all scans)
 
 It also writes and re-reads the drive in the reference's wire formats: lidar lines
 `timestamp_us;x1;y1;z1;x2;...` (services/lidar_service.py:5-19) and IMU lines
 `timestamp_us;qx;qy;qz;qw` (services/imu_service.py:1-38).
 
-    python examples/slam_loop.py [n_scans] [--imu]
+    python examples/slam_loop.py [n_scans] [--imu] [--loop]      (--loop: a closed circuit, 1.2 laps)
 """
 import os
 import sys
@@ -33,6 +36,8 @@ from icpmi.submap import RollingSubmap  # noqa: E402
 from utilities import features  # noqa: E402
 from utilities import icp as uicp  # noqa: E402
 from utilities.mapping import OccupancyGrid2D  # noqa: E402
+from utilities.pose_graph import PoseGraph2D, pose_matrix_to_vec, pose_vec_to_matrix, relative_transform_vec  # noqa: E402
+from utilities import pose_graph as upg  # noqa: E402
 
 
 # ── reference wire format ────────────────────────────────────────────────────
@@ -95,11 +100,11 @@ def pose_matrix(x, y, th):
     return np.array([[c, -s, x], [s, c, y], [0.0, 0.0, 1.0]])
 
 
-def run(n_scans=60, log_path=None, verbose=True, imu_path=None):
+def run(n_scans=60, log_path=None, verbose=True, imu_path=None, loop=False, use_submap=True, lc_error_threshold=0.05):
     from icpmi import submap as submap_mod
-    uicp.VERBOSE = features.VERBOSE = submap_mod.VERBOSE = False
+    uicp.VERBOSE = features.VERBOSE = submap_mod.VERBOSE = upg.VERBOSE = False
     segs = synth.maze_segments()
-    truth = synth.trajectory(n_scans, step=0.18)
+    truth = synth.loop_trajectory(n_scans) if loop else synth.trajectory(n_scans, step=0.18)
     scans = [synth.scan(p, 9000 + i, segs=segs) for i, p in enumerate(truth)]
     stamps = [1000000 + 100000 * i for i in range(n_scans)]
     if log_path:
@@ -115,7 +120,8 @@ def run(n_scans=60, log_path=None, verbose=True, imu_path=None):
     pose = pose_matrix(*truth[0])                       # start at the true pose; everything after is estimated
     submap = RollingSubmap(window=40, voxel_size=0.04)
     history, mapper, timing = [], None, {"s2s": 0.0, "submap": 0.0, "map": 0.0, "loop": 0.0}
-    closures, rejected = [], []
+    closures, rejected, accepted = [], [], []
+    graph = PoseGraph2D()
     prev = None
     for i, cur in enumerate(scans):
         if prev is not None:
@@ -138,7 +144,7 @@ def run(n_scans=60, log_path=None, verbose=True, imu_path=None):
                 rejected.append(i)                                            # keep the pose; the submap step may still fix it
             timing["s2s"] += time.perf_counter() - t0
             t0 = time.perf_counter()
-            if len(submap) >= 5:                                              # slam.py:505-536
+            if use_submap and len(submap) >= 5:                               # slam.py:505-536
                 Rs, ts, es = submap.attempt_icp(cur, pose, imu_yaw, 3.0, 60.0, 0.8, 0.1, 0.2, icp_cfg, 1.5)
                 dpos = np.linalg.norm(ts - pose[:2, 2])
                 dyaw = abs((np.arctan2(Rs[1, 0], Rs[0, 0]) - np.arctan2(pose[1, 0], pose[0, 0]) + np.pi) % (2 * np.pi) - np.pi)
@@ -155,6 +161,10 @@ def run(n_scans=60, log_path=None, verbose=True, imu_path=None):
         timing["map"] += time.perf_counter() - t0
         submap.push(world)
         history.append((cur, pose.copy()))
+        node = graph.add_node(pose_matrix_to_vec(pose))                      # slam.py:543-549: node + odometry edge
+        if node > 0:
+            odo_err = err if err <= 0.15 else 0.15
+            graph.add_edge(node - 1, node, relative_transform_vec(history[-2][1], pose), np.eye(3) / max(odo_err, 1e-6))
         # loop closure candidates: old scans near the current position, all registered in one batch (slam.py:566-597)
         t0 = time.perf_counter()
         if i >= 30 and i % 10 == 0:
@@ -163,6 +173,20 @@ def run(n_scans=60, log_path=None, verbose=True, imu_path=None):
                 R, t, err, info = batch.icp_batch(cur, [history[k][0] for k in cands], **icp_kw)
                 best = int(np.argmin(err))
                 closures.append((i, cands[best], float(err[best]), int(info["iters"][best])))
+                if err[best] < lc_error_threshold:                           # slam.py:582-620
+                    T_lc = np.eye(3)
+                    T_lc[:2, :2], T_lc[:2, 2] = R[best], t[best]              # cur -> candidate frame, so z = T_lc^-1
+                    graph.add_edge(node, cands[best], pose_matrix_to_vec(np.linalg.inv(T_lc)),
+                                   np.eye(3) * 10.0 / max(float(err[best]), 1e-6))
+                    before = pose[:2, 2].copy()
+                    graph.optimize(n_iterations=20, fix_node=0)
+                    history = [(pts, pose_vec_to_matrix(v)) for (pts, _), v in zip(history, graph.nodes)]
+                    pose = history[-1][1].copy()
+                    worlds = [pts @ T[:2, :2].T + T[:2, 2] for pts, T in history]
+                    submap.reset(worlds[-submap.window:])
+                    mapper.reset()                                            # _rebuild_map, slam.py:271-277
+                    mapper.update_scans(np.array([T[:2, 2] for _, T in history]), worlds)
+                    accepted.append((i, cands[best], float(np.linalg.norm(pose[:2, 2] - before)), dict(graph.last_info)))
         timing["loop"] += time.perf_counter() - t0
         prev = cur
     est = np.array([p[:2, 2] for _, p in history])
@@ -174,10 +198,15 @@ def run(n_scans=60, log_path=None, verbose=True, imu_path=None):
         print(f"{n_scans} scans: final position error {drift[-1]:.3f} m (max {drift.max():.3f} m over {np.sum(np.linalg.norm(np.diff(gt, axis=0), axis=1)):.1f} m driven)")
         print(f"map: {occupied} occupied / {free} free cells; scan-to-scan rejections at {rejected}; loop-closure checks: {closures}")
         print("wall ms per scan: " + ", ".join(f"{k} {v / n_scans * 1e3:.2f}" for k, v in timing.items()))
-    return dict(drift=drift, occupied=occupied, free=free, closures=closures, rejected=rejected, timing=timing)
+        if accepted:
+            print("closures accepted (scan, matched scan, pose moved by [m], iterations): "
+                  + ", ".join(f"({a}, {b}, {d:.3f}, {inf['iterations']})" for a, b, d, inf in accepted))
+    return dict(drift=drift, occupied=occupied, free=free, closures=closures, rejected=rejected, timing=timing,
+                accepted=accepted, graph=graph, mapper=mapper, history=history)
 
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     run(int(args[0]) if args else 60, log_path="/tmp/icpmi_demo_lidar.csv",
-        imu_path="/tmp/icpmi_demo_imu.csv" if "--imu" in sys.argv else None)
+        imu_path="/tmp/icpmi_demo_imu.csv" if "--imu" in sys.argv else None, loop="--loop" in sys.argv,
+        use_submap="--no-submap" not in sys.argv)

@@ -135,3 +135,13 @@ def trajectory(n, start=(5.0, 5.0, 0.0), step=0.25, segs=None, seed=3):
         x += step * np.cos(th)
         y += step * np.sin(th)
     return poses
+
+
+def loop_trajectory(n, center=(25.0, 15.0), radius=3.2, laps=1.2):
+    """A closed circuit (counter-clockwise circle, heading along the tangent) that overlaps itself after one
+    lap, for loop closures.  The default sits in a room of ``maze_segments()`` clear of its pillar."""
+    poses = []
+    for k in range(n):
+        a = 2.0 * np.pi * laps * k / max(n - 1, 1)
+        poses.append((center[0] + radius * np.cos(a), center[1] + radius * np.sin(a), a + np.pi / 2.0))
+    return poses

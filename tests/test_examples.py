@@ -67,3 +67,29 @@ def test_slam_loop_with_imu(tmp_path):
     out = m.run(36, log_path=str(tmp_path / "drive.csv"), verbose=False, imu_path=str(tmp_path / "imu.csv"))
     assert out["drift"].max() < 0.25, out["drift"].max()
     assert out["occupied"] > 1000 and out["free"] > 50000
+
+
+@pytest.mark.gpu
+def test_slam_loop_closes_the_loop():
+    """A circuit of 1.2 laps: closures are found, the pose graph is optimised, poses are rewritten and the map is
+    rebuilt by replaying every scan (slam.py:566-620)."""
+    m = _load()
+    out = m.run(81, verbose=False, loop=True)
+    assert len(out["accepted"]) >= 1, out["closures"]
+    for scan, matched, moved, info in out["accepted"]:
+        assert scan - matched >= 20 and info["status"] == 1 and info["iterations"] <= 20
+    assert out["drift"][-1] < 0.4, out["drift"][-1]
+    g = out["graph"]
+    assert len(g.nodes) == 81 and len(g.edges) == 80 + len(out["accepted"])
+    # the rebuilt map is exactly the replay of every scan at its corrected pose
+    from utilities.mapping import OccupancyGrid2D
+    mp = out["mapper"]
+    last = out["accepted"][-1][0]
+    ref = OccupancyGrid2D(mp.min_x, mp.max_x, mp.min_y, mp.max_y, resolution=0.05, p_hit=0.85, p_miss=0.42,
+                          log_odds_min=-8.0, log_odds_max=8.0)
+    assert (ref.ny, ref.nx) == (mp.ny, mp.nx)
+    assert last == 80, out["accepted"]                                # closed on the last scan: nothing was added after the rebuild
+    if last == 80:
+        for pts, T in out["history"]:
+            ref.update_scan(T[:2, 2], pts @ T[:2, :2].T + T[:2, 2])
+        assert np.array_equal(ref.log_odds, mp.log_odds)
