@@ -37,12 +37,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=512)
+    ap.add_argument("--pairs-per-gpu", type=int, default=8192,
+                    help="scan pairs resident per GPU; the few pairs that run to max_iterations leave most CUs idle at the "
+                         "end of a launch, so throughput grows with the batch (512: 6.3e6 it/s, 8192: 1.07e7 it/s)")
     ap.add_argument("--pairs-total", type=int, default=0,
                     help="strong scaling: this many pairs in all, split over the GPUs (BASELINE config 5 uses 512)")
     ap.add_argument("--raycast-scans", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raycast", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the main line (no single-pair, submap, ... legs)")
     args = ap.parse_args()
 
     import torch
@@ -127,13 +130,13 @@ def main():
                 "note": "algorithmic bytes = sum over pairs of iterations x (28 N + 16 M), N/M rows after voxel filtering"}
 
     # HBM bytes per launch from the PMC counters cannot be collected from inside this process: they come from the
-    # committed rocprofv3 --pmc passes of this very command (profiles/r01_pmc_traffic.json), same workload and grid.
+    # committed rocprofv3 --pmc passes of this very command (profiles/r01_pmc_traffic_b8192.json), same workload and grid.
     try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic_b8192.json")))["kernels"]
         key = [k for k in pmc if "icp2_fused_kernel" in k and f"[{B} workgroups]" in k]
         if batch.fast and key:
             roofline["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+            roofline["traffic_source"] = "profiles/r01_pmc_traffic_b8192.json (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
     except (OSError, KeyError, ValueError):
         pass
 
@@ -150,7 +153,7 @@ def main():
                        "includes": "voxel_downsample x2 + estimate_normals_2d + ICP loop + result all_gather"},
             "roofline": roofline}
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_extras:
         # single-pair latency (config 2 exactly as the reference calls it, one pair)
         one = IcpBatch([srcs[0], tgts[0]], [0], [1], **ICP_KW)
         for _ in range(3):
@@ -164,6 +167,7 @@ def main():
         it1 = float(one.results.cpu().numpy()[0, _lib.RES_ITERS])
         line["single_pair"] = {"ms_per_icp": round(lat * 1e3, 4), "iterations": it1,
                                "iterations_per_sec": round(it1 / lat, 1)}
+        line["pipelined"] = bench_pipelined(torch, IcpBatch, _lib, srcs, tgts, max(args.steps, 8))
         line["nn_exhaustive"] = bench_nn_exhaustive(torch, batch, _lib)
         line["submap"] = bench_submap(torch, synth, not args.no_cpu_baseline)
         line["scan_pair_host_api"] = bench_host_api(srcs[0], tgts[0], not args.no_cpu_baseline)
@@ -179,6 +183,34 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_pipelined(torch, IcpBatch, _lib, srcs, tgts, steps):
+    """Small batches (the 512 candidates of BASELINE config 5) one at a time and with 2 / 3 in flight on separate HIP
+    streams: the few pairs of a batch that run to max_iterations (alone on their CUs for half of the kernel) then
+    overlap the bulk of the next batch.  Not `value`: that line times one large batch at a time."""
+    B = min(512, len(srcs))
+    out = {"note": f"distinct resident batches of {B} pairs alternating over HIP streams; every step is the full hot path"}
+    batches = []
+    for depth in (1, 2, 3):
+        while len(batches) < depth:
+            lo = (len(batches) * B) % max(len(srcs) - B + 1, 1)
+            batches.append(IcpBatch(srcs[lo:lo + B] + tgts[lo:lo + B], np.arange(B), np.arange(B, 2 * B), **ICP_KW))
+        streams = [torch.cuda.Stream() for _ in range(depth)]
+        for k in range(depth):                                   # warm-up, also gives each batch's iteration count
+            with torch.cuda.stream(streams[k]):
+                batches[k].run()
+        torch.cuda.synchronize()
+        iters = [float(b.results.cpu().numpy()[:B, _lib.RES_ITERS].sum()) for b in batches[:depth]]
+        t0 = time.perf_counter()
+        for k in range(steps * depth):
+            with torch.cuda.stream(streams[k % depth]):
+                batches[k % depth].run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"in_flight_{depth}"] = {"iterations_per_sec": round(sum(iters) * steps / dt, 1),
+                                     "ms_per_step": round(dt / (steps * depth) * 1e3, 4)}
+    return out
 
 
 def bench_nn_exhaustive(torch, batch, _lib):
@@ -404,13 +436,14 @@ def cpu_baseline(srcs, tgts):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 64))
-    per_pair = dt / max(n, 1)
-    todo = max(cores, int(8.0 * cores / per_pair))                               # about 8 s of wall time
-    pairs = [(srcs[i % len(srcs)], tgts[i % len(tgts)]) for i in range(todo)]
+    cores = max(1, min(cores, 16))                                               # the box's CPU share for one GPU
+    pairs = [(srcs[i % len(srcs)], tgts[i % len(tgts)]) for i in range(cores * 16)]
     t0 = time.perf_counter()
+    it_all = todo = 0
     with ThreadPoolExecutor(cores) as ex:
-        it_all = sum(ex.map(lambda p: oracle.icp(p[0], p[1], **ICP_KW)[3]["iters"], pairs))
+        while time.perf_counter() - t0 < 8.0:                                    # rounds of 16 pairs per thread, about 8 s
+            it_all += sum(ex.map(lambda p: oracle.icp(p[0], p[1], **ICP_KW)[3]["iters"], pairs))
+            todo += len(pairs)
     dt_all = time.perf_counter() - t0
     out["all_cores"] = {"value": round(it_all / dt_all, 1), "unit": "iterations/s", "cores": cores, "kind": "port",
                         "sample": f"{todo} ICP calls on a {cores}-thread pool, {it_all} iterations, {dt_all:.1f} s"}
