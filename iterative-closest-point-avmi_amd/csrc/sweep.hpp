@@ -16,9 +16,14 @@
 
 namespace icpmi {
 
-// projection value along axis `dir`
+// projection value along axis `dir`: x, y, x + y, x - y.  Written as x*a + y*b with a in {1, 0} and b in
+// {0, 1, 1, -1} (every product and sum exact for finite coordinates): the axis is uniform, but selecting
+// the form inside a search loop costs a chain of scalar branches per candidate; the two factors are
+// loop invariant.
 __device__ __forceinline__ double proj(int dir, double x, double y) {
-    return dir == 0 ? x : (dir == 1 ? y : (dir == 2 ? x + y : x - y));
+    const double a = dir == 1 ? 0.0 : 1.0;
+    const double b = dir == 0 ? 0.0 : (dir == 3 ? -1.0 : 1.0);
+    return x * a + y * b;
 }
 
 // Lower bound on the squared distance implied by a projection gap, with the
