@@ -23,6 +23,22 @@ __device__ __forceinline__ void bitonic_sort_pairs(uint64_t* keys, uint32_t* row
         }
 }
 
+// The same network on ONE array of packed values (key << row_bits | row): a third (32-bit) or two thirds
+// (64-bit) of the LDS traffic of the pair sort, which is what bounds it.  Pad with all ones.
+template <typename T>
+__device__ __forceinline__ void bitonic_sort_packed(T* v, int npad) {
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = threadIdx.x; p < npad / 2; p += blockDim.x) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const int x = i | j;
+                const T a = v[i], b = v[x];
+                if ((a > b) == ((i & k) == 0)) { v[i] = b; v[x] = a; }
+            }
+            __syncthreads();
+        }
+}
+
 // Order-preserving map double -> uint64 (and back): a < b  <=>  enc(a) < enc(b).
 __device__ __forceinline__ uint64_t f64_sortable(double v) {
     const uint64_t b = (uint64_t)__double_as_longlong(v);

@@ -152,12 +152,45 @@ __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
     double mn[3], mx[3], ext[3];
     cloud_bounds<DIM>(P, n, mn, mx, dscratch);
     if (!key_extents<DIM>(mn, mx, voxel, ext)) { if (threadIdx.x == 0) out_cnt[c] = -1; return; }
-    for (int i = threadIdx.x; i < npad; i += VOX_THREADS) {
-        keys[i] = i < n ? vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel) : ~0ull;
-        rows[i] = i < n ? (uint32_t)i : 0xffffffffu;
+    // (key, row) sorts as ONE integer key << row_bits | row when that fits: the sort is bound by LDS traffic,
+    // and a 2 048-beam scan in a room needs ~18 + 11 bits
+    int row_bits = 6;
+    while ((1 << row_bits) < npad) ++row_bits;
+    double cells = 1.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) cells *= ext[d];                      // keys are below this product
+    const double packed_range = cells * (double)npad;                   // packed values are below this
+    if (packed_range < 4.0e9) {
+        uint32_t* pk = rows;                                             // sorted in the row array, unpacked in place
+        for (int i = threadIdx.x; i < npad; i += VOX_THREADS)
+            pk[i] = i < n ? (uint32_t)(vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel) << row_bits) | (uint32_t)i : 0xffffffffu;
+        __syncthreads();
+        bitonic_sort_packed<uint32_t>(pk, npad);
+        for (int i = threadIdx.x; i < npad; i += VOX_THREADS) {
+            const uint32_t v = pk[i];
+            keys[i] = v == 0xffffffffu ? ~0ull : (uint64_t)(v >> row_bits);
+            rows[i] = v == 0xffffffffu ? 0xffffffffu : (v & ((1u << row_bits) - 1u));
+        }
+        __syncthreads();
+    } else if (packed_range < 9.0e18) {
+        for (int i = threadIdx.x; i < npad; i += VOX_THREADS)
+            keys[i] = i < n ? (vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel) << row_bits) | (uint64_t)i : ~0ull;
+        __syncthreads();
+        bitonic_sort_packed<uint64_t>(keys, npad);
+        for (int i = threadIdx.x; i < npad; i += VOX_THREADS) {
+            const uint64_t v = keys[i];
+            keys[i] = v == ~0ull ? ~0ull : (v >> row_bits);
+            rows[i] = v == ~0ull ? 0xffffffffu : (uint32_t)(v & ((1ull << row_bits) - 1ull));
+        }
+        __syncthreads();
+    } else {
+        for (int i = threadIdx.x; i < npad; i += VOX_THREADS) {
+            keys[i] = i < n ? vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel) : ~0ull;
+            rows[i] = i < n ? (uint32_t)i : 0xffffffffu;
+        }
+        __syncthreads();
+        bitonic_sort_pairs(keys, rows, npad);     // == stable sort by key (rows are unique)
     }
-    __syncthreads();
-    bitonic_sort_pairs(keys, rows, npad);     // == stable sort by key (rows are unique)
     voxel_finish<DIM>(keys, rows, n, P, O, out_cnt + c, iscratch);
 }
 
