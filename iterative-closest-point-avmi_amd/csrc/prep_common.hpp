@@ -62,35 +62,35 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
     return dir;
 }
 
-// k best (d2, row, sorted position), ascending by (d2, row).  Every index is a
-// compile-time constant (template recursion), so the lists stay in registers.
+// k best (d2, sorted position), ascending by (d2, original row).  Every index is a compile-time constant
+// (template recursion), so the lists stay in registers.  The rows are not kept: they only order candidates
+// at exactly equal distances, where they are read from `sorig` (LDS / L2) on the spot.
 template <int KK>
 struct TopKP {
     double d[KK];
-    int j[KK];
     int p[KK];
     template <int I>
     __device__ __forceinline__ void init_from() {
-        if constexpr (I < KK) { d[I] = __builtin_inf(); j[I] = 0x7fffffff; p[I] = 0; init_from<I + 1>(); }
+        if constexpr (I < KK) { d[I] = __builtin_inf(); p[I] = 0; init_from<I + 1>(); }
     }
     __device__ __forceinline__ void init() { init_from<0>(); }
     template <int I>
-    __device__ __forceinline__ void bubble() {
+    __device__ __forceinline__ void bubble(const int32_t* sorig) {
         if constexpr (I > 0) {
             // stop as soon as the new entry is in place: candidates arrive roughly by
             // increasing distance, so most insertions move one or two slots
-            if (d[I] < d[I - 1] || (d[I] == d[I - 1] && j[I] < j[I - 1])) {
-                const double td = d[I - 1]; const int tj = j[I - 1], tp = p[I - 1];
-                d[I - 1] = d[I]; j[I - 1] = j[I]; p[I - 1] = p[I];
-                d[I] = td; j[I] = tj; p[I] = tp;
-                bubble<I - 1>();
+            if (d[I] < d[I - 1] || (d[I] == d[I - 1] && sorig[p[I]] < sorig[p[I - 1]])) {
+                const double td = d[I - 1]; const int tp = p[I - 1];
+                d[I - 1] = d[I]; p[I - 1] = p[I];
+                d[I] = td; p[I] = tp;
+                bubble<I - 1>(sorig);
             }
         }
     }
-    __device__ __forceinline__ bool push(double s, int row, int pos) {
-        if (s < d[KK - 1] || (s == d[KK - 1] && row < j[KK - 1])) {
-            d[KK - 1] = s; j[KK - 1] = row; p[KK - 1] = pos;
-            bubble<KK - 1>();
+    __device__ __forceinline__ bool push(double s, int pos, const int32_t* sorig) {
+        if (s < d[KK - 1] || (s == d[KK - 1] && sorig[pos] < sorig[p[KK - 1]])) {
+            d[KK - 1] = s; p[KK - 1] = pos;
+            bubble<KK - 1>(sorig);
             return true;
         }
         return false;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* 
         const double uq = proj(dir, q.x, q.y);
         TopKP<KK> top;
         top.init();
-        top.push(0.0, sorig[s], s);
+        top.push(0.0, s, sorig);
         // the sweep on one side ends when the gap along the axis alone exceeds the current kk-th best
         // distance (inf until kk neighbours are known), compared in squares: no sqrt on the path
         // (gap_exceeds, sweep.hpp: exact on x / y; the diagonals allow for the rounding of x +- y)
@@ -144,7 +144,7 @@ __device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* 
                         double d2 = 0.0;
                         d2 += dx * dx;
                         d2 += dy * dy;
-                        if (top.push(d2, sorig[i], i)) bound = (kk == KK ? top.d[KK - 1] : top.kth(kk - 1)) * widen;
+                        if (top.push(d2, i, sorig)) bound = (kk == KK ? top.d[KK - 1] : top.kth(kk - 1)) * widen;
                         if (right) ++hi; else --lo;
                     }
                 }
