@@ -156,14 +156,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         # single-pair latency (config 2 exactly as the reference calls it, one pair)
         one = IcpBatch([srcs[0], tgts[0]], [0], [1], **ICP_KW)
-        for _ in range(3):
-            one.run()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(50):
-            one.run()
-        torch.cuda.synchronize()
-        lat = (time.perf_counter() - t1) / 50
+        lat = timed(torch, one.run)
         it1 = float(one.results.cpu().numpy()[0, _lib.RES_ITERS])
         line["single_pair"] = {"ms_per_icp": round(lat * 1e3, 4), "iterations": it1,
                                "iterations_per_sec": round(it1 / lat, 1)}
@@ -183,6 +176,25 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def timed(torch, fn, warm_s=0.1, min_s=0.15):
+    """Seconds per call of fn (which enqueues GPU work): at least warm_s of untimed calls first — the short legs run
+    after seconds of host-side setup, and a GPU that has idled takes a while to clock up again — then at least
+    min_s of timed calls, synchronised at both ends."""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < warm_s:
+        fn()
+    torch.cuda.synchronize()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        if n % 8 == 0:
+            torch.cuda.synchronize()
+            if time.perf_counter() - t0 >= min_s:
+                break
+    return (time.perf_counter() - t0) / n
 
 
 def bench_pipelined(torch, IcpBatch, _lib, srcs, tgts, steps):
@@ -258,15 +270,10 @@ def bench_host_api(src, tgt, with_cpu):
         R0, t0, _ = features.rotation_search(src, tgt, voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
         return uicp.ICP(src, tgt, R_init=R0, t_init=t0, **kw)
 
-    pair()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        features.rotation_search(src, tgt, voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
-    rs_ms = (time.perf_counter() - t0) / 20 * 1e3
-    t0 = time.perf_counter()
-    for _ in range(20):
-        pair()
-    pair_ms = (time.perf_counter() - t0) / 20 * 1e3
+    import torch
+    rs_ms = timed(torch, lambda: features.rotation_search(src, tgt, voxel_size=0.15, angle_step_coarse=1.5,
+                                                          angle_step_fine=0.1)) * 1e3
+    pair_ms = timed(torch, pair) * 1e3
     out = {"rotation_search_ms": round(rs_ms, 3), "run_icp_pair_ms": round(pair_ms, 3),
            "reference_python_ms": {"rotation_search": 73.0, "run_icp_pair": 149.0,
                                    "note": "survey container, 1 core (BASELINE.md section 2), not this box"}}
@@ -289,12 +296,7 @@ def bench_submap(torch, synth, with_cpu):
     allpts = np.vstack([synth.to_world(synth.scan(p, 500 + i, segs=segs), p) for i, p in enumerate(poses)])
     cs = CloudSet.from_numpy([allpts])
     out = voxel_downsample_set(cs, 0.04)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        voxel_downsample_set(cs, 0.04, out=out)
-    torch.cuda.synchronize()
-    vox_ms = (time.perf_counter() - t0) / 10 * 1e3
+    vox_ms = timed(torch, lambda: voxel_downsample_set(cs, 0.04, out=out)) * 1e3
     sub = out.to_numpy()[0]
     pose = poses[-1]
     cur = synth.scan(pose, 999, segs=segs)
@@ -304,14 +306,7 @@ def bench_submap(torch, synth, with_cpu):
     kw = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, R_init=R0, t_init=t0v,
               method="point_to_point", max_corr_dist=1.5)
     b = IcpBatch([cur, sub], [0], [1], **kw)
-    for _ in range(3):
-        b.run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        b.run()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 20 * 1e3
+    ms = timed(torch, b.run) * 1e3
     it = float(b.results.cpu().numpy()[0, 14])
     res = {"workload": f"config 3: 2048-beam scan vs {len(sub)}-point submap, point_to_point, max_corr_dist 1.5",
            "ms_per_icp": round(ms, 4), "iterations": it, "iterations_per_sec": round(it / (ms * 1e-3), 1),
@@ -383,8 +378,10 @@ def bench_raycast(torch, synth, n_scans, with_cpu):
     d_hits = torch.from_numpy(np.concatenate(hits)).cuda()
     off = np.zeros(n_scans + 1, dtype=np.int32)
     np.cumsum([len(h) for h in hits], out=off[1:])
-    g._apply(d_org, d_hits, off)                                 # warm-up
-    g.reset()
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.1:                       # warm-up replays (see timed())
+        g._apply(d_org, d_hits, off)
+        g.reset()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
