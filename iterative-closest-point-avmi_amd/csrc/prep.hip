@@ -13,8 +13,8 @@ constexpr int PREP_THREADS = 512;
 constexpr int PREP_MAXW = PREP_THREADS / ICPMI_WAVE;
 constexpr int PREP_MAX_POINTS = 4096;   // sorted copy (20 B/pt) + sort scratch (12 B/pt) stay in LDS
 
-// KK = capacity of the per-query neighbour list (0: no normals)
-template <int KK>
+// KK = capacity of the per-query neighbour list (0: no normals); GRID: k-NN through a grid instead of the sweep
+template <int KK, bool GRID>
 __global__ __launch_bounds__(PREP_THREADS, (KK <= 16 ? 4 : 2)) void prep_targets_kernel(   // two workgroups per CU up to KK = 16
     const double* __restrict__ pts, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
     const int32_t* __restrict__ cloud_ids, int k, double2* __restrict__ g_sxy, double2* __restrict__ g_snrm,
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 16 ? 4 : 2)) void prep_targets
     uint64_t* keys = reinterpret_cast<uint64_t*>(dyn + (size_t)lds_points * 20);      // npad * 8 B
     uint32_t* rows = reinterpret_cast<uint32_t*>(dyn + (size_t)lds_points * 20 + (size_t)npad * 8);
 
-    const int dir = choose_axis<PREP_THREADS>(P, M, dsc, hist);
+    double bounds[4];
+    const int dir = choose_axis<PREP_THREADS>(P, M, dsc, hist, bounds);
     // ── sort along the chosen axis ──────────────────────────────────────────
     for (int i = threadIdx.x; i < npad; i += PREP_THREADS) {
         keys[i] = i < M ? f64_sortable(proj(dir, P[2 * i], P[2 * i + 1])) : ~0ull;
@@ -62,7 +63,20 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 16 ? 4 : 2)) void prep_targets
         double2* o_snrm = g_snrm + off[c];
         double* o_rows = out_normals ? out_normals + (size_t)off[c] * 2 : nullptr;
         const int per = (M + split - 1) / split;
-        prep_normals<KK>(sxy, sorig, M, min(M, part * per), min(M, (part + 1) * per), dir, kk, o_snrm, o_rows);
+        if constexpr (GRID) {
+            // Few clouds (a single scan pair): the time of the launch is the longest search of any lane, and a
+            // grid bounds that far better than a 1-D window (a wall across the sweep axis puts hundreds of
+            // points in it).  Built in the LDS the sort has released: cell ends (4 B per cell), then positions
+            // by cell.  Same neighbours, same order.
+            const int cells_cap = min(4096, 2 * npad);
+            uint32_t* cell_end = reinterpret_cast<uint32_t*>(keys);
+            uint16_t* cell_pts = reinterpret_cast<uint16_t*>(cell_end + cells_cap);
+            const PrepGrid grid = prep_grid_build(sxy, M, bounds, kk, cell_end, cell_pts, cells_cap, hist);
+            prep_normals_grid<KK>(sxy, sorig, M, min(M, part * per), min(M, (part + 1) * per), kk, grid, o_snrm, o_rows);
+        } else {
+            // Many clouds: every CU is busy, the sum of the work counts, and the sweep has less of it per candidate.
+            prep_normals<KK>(sxy, sorig, M, min(M, part * per), min(M, (part + 1) * per), dir, kk, o_snrm, o_rows);
+        }
     }
 }
 
@@ -127,14 +141,20 @@ extern "C" int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, 
     const size_t lds = (size_t)npad * 20 + (size_t)npad * 12;      // lds_points = npad; larger clouds are skipped in-kernel
     int split = 256 / n_sel;                 // a workgroup for every CU when the batch is small
     split = split < 1 ? 1 : (split > 16 ? 16 : split);
-#define ICPMI_PREP_GO(KKV)                                                                                              \
+    // k-NN search of the normals: grid for few clouds, sweep for many (see the kernel); ICPMI_PREP_KNN=grid|sweep
+    // forces one of the two (tests run both on the same inputs)
+    int use_grid = split > 1;
+    if (const char* env = getenv("ICPMI_PREP_KNN")) use_grid = env[0] == 'g' ? 1 : (env[0] == 's' ? 0 : use_grid);
+#define ICPMI_PREP_GO2(KKV, G)                                                                                          \
     do {                                                                                                                \
-        if (hipFuncSetAttribute((const void*)prep_targets_kernel<KKV>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+        if (hipFuncSetAttribute((const void*)prep_targets_kernel<KKV, G>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                 (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                          \
-        prep_targets_kernel<KKV><<<n_sel * (KKV > 0 ? split : 1), PREP_THREADS, lds, st>>>(                             \
+        prep_targets_kernel<KKV, G><<<n_sel * (KKV > 0 ? split : 1), PREP_THREADS, lds, st>>>(                          \
             pts, off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig, g_dir, out_normals, npad,               \
             KKV > 0 ? split : 1);                                                                                       \
     } while (0)
+#define ICPMI_PREP_GO(KKV)                                                                                              \
+    do { if (use_grid && KKV > 0) ICPMI_PREP_GO2(KKV, true); else ICPMI_PREP_GO2(KKV, false); } while (0)
     // list capacity = k + 1 exactly for the usual k (5, 10 = reference default, 12 = config.yaml), else the next size up
     if (normal_k < 0) ICPMI_PREP_GO(0);
     else if (normal_k + 1 <= 6) ICPMI_PREP_GO(6);
@@ -143,6 +163,7 @@ extern "C" int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, 
     else if (normal_k + 1 <= 13) ICPMI_PREP_GO(13);
     else if (normal_k + 1 <= 16) ICPMI_PREP_GO(16);
     else ICPMI_PREP_GO(32);
+#undef ICPMI_PREP_GO2
 #undef ICPMI_PREP_GO
     ICPMI_LAUNCH_CHECK();
     return ICPMI_OK;

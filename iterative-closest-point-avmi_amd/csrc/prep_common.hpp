@@ -12,8 +12,9 @@ constexpr int PREP_BINS = 64;
 // the axis with the smallest expected search window (sum of squared bin counts / bin width; the diagonals
 // pay sqrt(2) because their projection gap bounds the distance only up to that factor).  All threads of the
 // workgroup call it and get the same answer.  dsc: 8 * THREADS/64 doubles, hist: 4 * PREP_BINS ints of LDS.
+// bounds (optional): min x, max x, min y, max y of the cloud.
 template <int THREADS>
-__device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, double* dsc, int* hist) {
+__device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, double* dsc, int* hist, double* bounds = nullptr) {
     constexpr int MAXW = THREADS / ICPMI_WAVE;
     double mn[4], mx[4];
 #pragma unroll
@@ -48,6 +49,7 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
         }
     }
     __syncthreads();
+    if (bounds) { bounds[0] = mn[0]; bounds[1] = mx[0]; bounds[2] = mn[1]; bounds[3] = mx[1]; }
     int dir = 0;
     double bestc = __builtin_inf();
 #pragma unroll
@@ -111,6 +113,32 @@ struct TopKP {
     }
 };
 
+// np.cov over the kk neighbours of sorted position s (summed in ascending (distance, row) order), eigenvector of the
+// smaller eigenvalue, unit length (icp.py:66-76); written to the sorted copy and, optionally, to the row layout.
+template <int KK>
+__device__ __forceinline__ void emit_normal(const TopKP<KK>& top, int kk, const double2* sxy, const int32_t* sorig, int s,
+                                            double2* __restrict__ out_sorted, double* __restrict__ out_rows) {
+    double mx = 0.0, my = 0.0;
+    top.template for_first<0>(kk, [&](int pos) { const double2 c = sxy[pos]; mx += c.x; my += c.y; });
+    mx /= (double)kk; my /= (double)kk;
+    double sxx = 0.0, sxy_ = 0.0, syy = 0.0;
+    top.template for_first<0>(kk, [&](int pos) {
+        const double2 c = sxy[pos];
+        const double dx = c.x - mx, dy = c.y - my;
+        sxx += dx * dx; sxy_ += dx * dy; syy += dy * dy;
+    });
+    double vx = 1.0, vy = 0.0;
+    if (kk > 1) {
+        const double den = (double)(kk - 1);                 // np.cov ddof = 1
+        smallest_evec_2x2(sxx / den, sxy_ / den, syy / den, vx, vy);
+    }
+    double nn = sqrt(vx * vx + vy * vy);
+    nn = nn < 1e-10 ? 1e-10 : nn;                            // icp.py:74-75
+    const double2 n2 = make_double2(vx / nn, vy / nn);
+    out_sorted[s] = n2;
+    if (out_rows) { const int row = sorig[s]; out_rows[2 * row] = n2.x; out_rows[2 * row + 1] = n2.y; }
+}
+
 template <int KK>
 __device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* sorig, int M, int s_begin, int s_end, int dir, int kk,
                                              double2* __restrict__ out_sorted, double* __restrict__ out_rows) {
@@ -150,26 +178,116 @@ __device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* 
                 }
             }
         }
-        // np.cov over the kk neighbours, summed in ascending (distance, row) order
-        double mx = 0.0, my = 0.0;
-        top.template for_first<0>(kk, [&](int pos) { const double2 c = sxy[pos]; mx += c.x; my += c.y; });
-        mx /= (double)kk; my /= (double)kk;
-        double sxx = 0.0, sxy_ = 0.0, syy = 0.0;
-        top.template for_first<0>(kk, [&](int pos) {
-            const double2 c = sxy[pos];
-            const double dx = c.x - mx, dy = c.y - my;
-            sxx += dx * dx; sxy_ += dx * dy; syy += dy * dy;
-        });
-        double vx = 1.0, vy = 0.0;
-        if (kk > 1) {
-            const double den = (double)(kk - 1);                 // np.cov ddof = 1
-            smallest_evec_2x2(sxx / den, sxy_ / den, syy / den, vx, vy);
+        emit_normal<KK>(top, kk, sxy, sorig, s, out_sorted, out_rows);
+    }
+}
+
+// Grid over the cloud for the k-NN search of the normals (LDS, built in the scratch the sort has released):
+// cell_end[c] = end of cell c in cell_pts (its start is cell_end[c-1]), cell_pts = sorted positions by cell.
+struct PrepGrid {
+    double min_x, min_y, h;
+    int nx, ny;
+    const uint32_t* cell_end;
+    const uint16_t* cell_pts;
+};
+
+__device__ __forceinline__ int grid_cell_1d(double v, double mn, double h, int n) {
+    const int c = (int)floor((v - mn) / h);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+// Build the grid (all threads of the workgroup).  bounds: min x, max x, min y, max y.  kk scales the cell so
+// that the kk-th neighbour of a point on a wall lies about one cell away: points at spacing ~ perimeter / M.
+__device__ __forceinline__ PrepGrid prep_grid_build(const double2* sxy, int M, const double* bounds, int kk, uint32_t* cell_end,
+                                                    uint16_t* cell_pts, int cells_cap, int* wave_tot) {
+    PrepGrid g;
+    g.min_x = bounds[0]; g.min_y = bounds[2];
+    const double w = bounds[1] - bounds[0], hg = bounds[3] - bounds[2];
+    double h = 0.55 * (double)kk * 2.0 * (w + hg) / (double)M;
+    if (!(h > 0.0) || !(h < 1e300)) h = 1.0;
+    int nx, ny;
+    for (;;) {
+        const double fx = floor(w / h) + 1.0, fy = floor(hg / h) + 1.0;
+        if (fx * fy <= (double)cells_cap) { nx = (int)fx; ny = (int)fy; break; }
+        h *= 1.3;
+    }
+    g.h = h; g.nx = nx; g.ny = ny;
+    g.cell_end = cell_end; g.cell_pts = cell_pts;
+    const int nc = nx * ny;
+    for (int c = threadIdx.x; c < nc; c += blockDim.x) cell_end[c] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        const double2 p = sxy[i];
+        atomicAdd(&cell_end[grid_cell_1d(p.y, g.min_y, h, ny) * nx + grid_cell_1d(p.x, g.min_x, h, nx)], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the counts, in place: consecutive chunks per thread, wave scan of the chunk sums,
+    // wave totals through `wave_tot` (one int per wave of LDS)
+    {
+        const int per = (nc + (int)blockDim.x - 1) / (int)blockDim.x;
+        const int lo = min(nc, (int)threadIdx.x * per), hi = min(nc, lo + per);
+        uint32_t sum = 0;
+        for (int c = lo; c < hi; ++c) sum += cell_end[c];
+        uint32_t inc = sum;
+#pragma unroll
+        for (int o = 1; o < ICPMI_WAVE; o <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)inc, o, ICPMI_WAVE);
+            if (lane_id() >= o) inc += t;
         }
-        double nn = sqrt(vx * vx + vy * vy);
-        nn = nn < 1e-10 ? 1e-10 : nn;                            // icp.py:74-75
-        const double2 n2 = make_double2(vx / nn, vy / nn);
-        out_sorted[s] = n2;
-        if (out_rows) { const int row = sorig[s]; out_rows[2 * row] = n2.x; out_rows[2 * row + 1] = n2.y; }
+        if (lane_id() == ICPMI_WAVE - 1) wave_tot[wave_id()] = (int)inc;
+        __syncthreads();
+        uint32_t run = inc - sum;
+        for (int w = 0; w < wave_id(); ++w) run += (uint32_t)wave_tot[w];
+        for (int c = lo; c < hi; ++c) { const uint32_t n = cell_end[c]; cell_end[c] = run; run += n; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {               // fill: cursor = start, ends as the cell's end
+        const double2 p = sxy[i];
+        const uint32_t slot = atomicAdd(&cell_end[grid_cell_1d(p.y, g.min_y, h, ny) * nx + grid_cell_1d(p.x, g.min_x, h, nx)], 1u);
+        cell_pts[slot] = (uint16_t)i;
+    }
+    __syncthreads();
+    return g;
+}
+
+// estimate_normals_2d over the grid: rings of cells around the query's cell until the kk-th best distance is
+// below the distance to every cell not yet visited (k rings done -> everything else is farther than k*h).
+// Exact: the same (distance, row) order decides, only the candidates that cannot enter the list are skipped.
+template <int KK>
+__device__ __forceinline__ void prep_normals_grid(const double2* sxy, const int32_t* sorig, int M, int s_begin, int s_end, int kk,
+                                                  const PrepGrid g, double2* __restrict__ out_sorted, double* __restrict__ out_rows) {
+    for (int s = s_begin + threadIdx.x; s < s_end; s += blockDim.x) {
+        const double2 q = sxy[s];
+        TopKP<KK> top;
+        top.init();
+        const int cx = grid_cell_1d(q.x, g.min_x, g.h, g.nx), cy = grid_cell_1d(q.y, g.min_y, g.h, g.ny);
+        const int kmax = max(max(cx, g.nx - 1 - cx), max(cy, g.ny - 1 - cy));
+        for (int k = 0; k <= kmax; ++k) {
+            // the 8k cells of ring k through ONE loop (one copy of the list insertion in the code): first the two
+            // full rows cy -+ k, then the two columns cx -+ k between them
+            const int n_row = k == 0 ? 1 : 2 * (2 * k + 1), n_ring = k == 0 ? 1 : 8 * k;
+            for (int idx = 0; idx < n_ring; ++idx) {
+                int xx, yy;
+                if (idx < n_row) { xx = cx - k + (idx >> 1); yy = (idx & 1) ? cy + k : cy - k; }
+                else { const int j = idx - n_row; yy = cy - k + 1 + (j >> 1); xx = (j & 1) ? cx + k : cx - k; }
+                if (xx < 0 || xx >= g.nx || yy < 0 || yy >= g.ny) continue;
+                const int c = yy * g.nx + xx;
+                const uint32_t e = g.cell_end[c];
+                for (uint32_t t = c ? g.cell_end[c - 1] : 0u; t < e; ++t) {
+                    const int i = g.cell_pts[t];
+                    const double2 p = sxy[i];
+                    const double dx = q.x - p.x, dy = q.y - p.y;
+                    double d2 = 0.0;
+                    d2 += dx * dx;
+                    d2 += dy * dy;
+                    top.push(d2, i, sorig);
+                }
+            }
+            const double kth = kk == KK ? top.d[KK - 1] : top.kth(kk - 1);
+            const double reach = (double)k * g.h;
+            if (kth < reach * reach * 0.999999999) break;              // nothing farther out can enter (or tie)
+        }
+        emit_normal<KK>(top, kk, sxy, sorig, s, out_sorted, out_rows);
     }
 }
 

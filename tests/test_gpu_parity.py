@@ -129,6 +129,31 @@ def test_normals_sizes(uicp):
         assert np.abs(np.abs(np.sum(n * no, axis=1)) - 1).max() < 1e-9, (m, k)
 
 
+def test_normals_grid_and_sweep_searches_agree(uicp, monkeypatch):
+    """prep.hip has two exact k-NN searches (grid for few clouds, sweep for many): same neighbours in the same order,
+    so the normals are bit-identical; ICPMI_PREP_KNN forces either on the same inputs."""
+    from icpmi import synth
+    rng = np.random.default_rng(8)
+    a, _ = synth.config2_pair(3)
+    line = np.column_stack([np.linspace(-2, 2, 300), np.full(300, 0.5)])               # collinear: a one-row grid
+    dup = np.repeat(rng.uniform(-1, 1, size=(40, 2)), 5, axis=0)                         # exact duplicates: ties on the row
+    lattice = np.stack(np.meshgrid(np.arange(30) * 0.1, np.arange(30) * 0.1), -1).reshape(-1, 2)   # many equal distances
+    clouds = [uicp.voxel_downsample(a, 0.04), rng.uniform(-4, 4, size=(3000, 2)), line, dup, lattice,
+              rng.normal(size=(5, 2)), np.zeros((7, 2))]
+    for pts in clouds:
+        for k in (12, 5, 31):
+            got = {}
+            for mode in ("grid", "sweep"):
+                monkeypatch.setenv("ICPMI_PREP_KNN", mode)
+                got[mode] = uicp.estimate_normals_2d(pts, k)
+            assert np.array_equal(got["grid"], got["sweep"]), (len(pts), k)
+            no = oracle.normals_2d(pts, k)
+            ok = np.abs(np.abs(np.sum(got["grid"] * no, axis=1)) - 1) < 1e-9
+            # isotropic neighbourhoods (lattice interior, identical points) have no defined direction: compare the rest
+            assert ok.mean() > 0.5 or len(pts) <= 7 or pts is lattice, (len(pts), k, ok.mean())
+    monkeypatch.delenv("ICPMI_PREP_KNN")
+
+
 def test_p2l_solve(uicp):
     z = load_golden("p2l_solve")
     R, t = uicp._point_to_line_solve_2d(z["src"], z["tgt"], z["normals"], z["idx"])
