@@ -15,7 +15,7 @@ constexpr int PREP_MAX_POINTS = 4096;   // sorted copy (20 B/pt) + sort scratch 
 
 // KK = capacity of the per-query neighbour list (0: no normals); GRID: k-NN through a grid instead of the sweep
 template <int KK, bool GRID>
-__global__ __launch_bounds__(PREP_THREADS, (KK <= 16 ? 4 : 2)) void prep_targets_kernel(   // two workgroups per CU up to KK = 16
+__global__ __launch_bounds__(PREP_THREADS, (KK <= 16 ? 4 : 2)) void prep_targets_kernel(   // at least two workgroups per CU up to KK = 16
     const double* __restrict__ pts, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
     const int32_t* __restrict__ cloud_ids, int k, double2* __restrict__ g_sxy, double2* __restrict__ g_snrm,
     int32_t* __restrict__ g_sorig, int32_t* __restrict__ g_dir, double* __restrict__ out_normals, int lds_points,
@@ -35,8 +35,12 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 16 ? 4 : 2)) void prep_targets
     while (npad < M) npad <<= 1;
     double2* sxy = reinterpret_cast<double2*>(dyn);                                   // lds_points * 16 B
     int32_t* sorig = reinterpret_cast<int32_t*>(dyn + (size_t)lds_points * 16);       // lds_points * 4 B
-    uint64_t* keys = reinterpret_cast<uint64_t*>(dyn + (size_t)lds_points * 20);      // npad * 8 B
-    uint32_t* rows = reinterpret_cast<uint32_t*>(dyn + (size_t)lds_points * 20 + (size_t)npad * 8);
+    // sort scratch (npad * 12 B): behind the sorted copy when the grid needs it afterwards, otherwise ON the sorted
+    // copy (the sorted rows pass through registers) — 32 KB instead of 56 KB for ~1 500 points, so that the k-NN
+    // loops of three workgroups instead of two share a CU
+    const size_t scratch_at = GRID ? (size_t)lds_points * 20 : 0;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(dyn + scratch_at);                   // npad * 8 B
+    uint32_t* rows = reinterpret_cast<uint32_t*>(dyn + scratch_at + (size_t)npad * 8);
 
     double bounds[4];
     const int dir = choose_axis<PREP_THREADS>(P, M, dsc, hist, bounds);
@@ -49,11 +53,22 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 16 ? 4 : 2)) void prep_targets
     bitonic_sort_pairs(keys, rows, npad);
     double2* o_sxy = g_sxy + off[c];
     int32_t* o_sorig = g_sorig + off[c];
-    for (int i = threadIdx.x; i < M; i += PREP_THREADS) {
-        const int row = (int)rows[i];
-        const double2 p = make_double2(P[2 * row], P[2 * row + 1]);
-        sxy[i] = p; sorig[i] = row;
-        if (part == 0) { o_sxy[i] = p; o_sorig[i] = row; }
+    int my_row[PREP_MAX_POINTS / PREP_THREADS];
+#pragma unroll
+    for (int u = 0; u < PREP_MAX_POINTS / PREP_THREADS; ++u) {
+        const int i = u * PREP_THREADS + (int)threadIdx.x;
+        my_row[u] = i < M ? (int)rows[i] : 0;
+    }
+    __syncthreads();                                             // the scratch may be the memory written next
+#pragma unroll
+    for (int u = 0; u < PREP_MAX_POINTS / PREP_THREADS; ++u) {
+        const int i = u * PREP_THREADS + (int)threadIdx.x;
+        if (i < M) {
+            const int row = my_row[u];
+            const double2 p = make_double2(P[2 * row], P[2 * row + 1]);
+            sxy[i] = p; sorig[i] = row;
+            if (part == 0) { o_sxy[i] = p; o_sorig[i] = row; }
+        }
     }
     if (threadIdx.x == 0 && part == 0) g_dir[c] = dir;
     __syncthreads();
@@ -138,7 +153,11 @@ extern "C" int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, 
     }
     int npad = 64;
     while (npad < small_max) npad <<= 1;
-    const size_t lds = (size_t)npad * 20 + (size_t)npad * 12;      // lds_points = npad; larger clouds are skipped in-kernel
+    // sorted copy: 20 B per point, sized to the largest cloud (rounded to 64); sort scratch: 12 B per padded slot.
+    // With ~1 500-point clouds this is 53 KB instead of 64 KB: three workgroups per CU instead of two.
+    const int lds_points = (small_max + 63) / 64 * 64;
+    const size_t lds_sep = (size_t)lds_points * 20 + (size_t)npad * 12;                     // grid instantiation
+    const size_t lds_alias = (size_t)lds_points * 20 > (size_t)npad * 12 ? (size_t)lds_points * 20 : (size_t)npad * 12;
     int split = 256 / n_sel;                 // a workgroup for every CU when the batch is small
     split = split < 1 ? 1 : (split > 16 ? 16 : split);
     // k-NN search of the normals: grid for few clouds, sweep for many (see the kernel); ICPMI_PREP_KNN=grid|sweep
@@ -147,10 +166,11 @@ extern "C" int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, 
     if (const char* env = getenv("ICPMI_PREP_KNN")) use_grid = env[0] == 'g' ? 1 : (env[0] == 's' ? 0 : use_grid);
 #define ICPMI_PREP_GO2(KKV, G)                                                                                          \
     do {                                                                                                                \
+        const size_t lds = G ? lds_sep : lds_alias;                                                                     \
         if (hipFuncSetAttribute((const void*)prep_targets_kernel<KKV, G>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                 (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                          \
         prep_targets_kernel<KKV, G><<<n_sel * (KKV > 0 ? split : 1), PREP_THREADS, lds, st>>>(                          \
-            pts, off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig, g_dir, out_normals, npad,               \
+            pts, off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig, g_dir, out_normals, lds_points,         \
             KKV > 0 ? split : 1);                                                                                       \
     } while (0)
 #define ICPMI_PREP_GO(KKV)                                                                                              \
