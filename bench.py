@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=8192,
                     help="scan pairs resident per GPU; the few pairs that run to max_iterations leave most CUs idle at the "
-                         "end of a launch, so throughput grows with the batch (512: 6.8e6 it/s, 8192: 1.19e7 it/s)")
+                         "end of a launch, so throughput grows with the batch (512: 6.8e6 it/s, 8192: 1.33e7 it/s)")
     ap.add_argument("--pairs-total", type=int, default=0,
                     help="strong scaling: this many pairs in all, split over the GPUs (BASELINE config 5 uses 512)")
     ap.add_argument("--raycast-scans", type=int, default=200)
