@@ -235,11 +235,28 @@ __device__ __forceinline__ float apply_counts(float v0, uint32_t H, uint32_t M, 
     return v;
 }
 
+// A group of consecutive scans counted in ONE launch, each into its own counter grid (cells are independent and
+// the finalise pass replays the grids in scan order, so the result is the sequential one bit for bit); the
+// launches of a replay drop from one per scan to one per group.
+#ifndef ICPMI_RC_GROUP
+#define ICPMI_RC_GROUP 8
+#endif
+constexpr int RC_GROUP_MAX = ICPMI_RC_GROUP;
+struct ScanGroup {
+    int n;                               // scans in the group
+    int first_block[RC_GROUP_MAX + 1];   // counting workgroups of scan s: [first_block[s], first_block[s + 1])
+    int nb[RC_GROUP_MAX];                // beams
+    int origin_row[RC_GROUP_MAX];        // row of the scan in `origins`
+    long long hit_row[RC_GROUP_MAX];     // first row of the scan in `hits`
+};
+
 struct FinArgs {
     float* log_odds;
-    uint32_t* counts;
+    uint32_t* counts;     // first counter grid of the group
+    size_t grid_stride;   // cells between the counter grids of consecutive scans of the group
+    int n_grids;          // scans in the group (1 for the single-scan paths)
     const BBox* bbox;
-    BBox* other;          // bounding-box slot to zero for a later scan (may be null)
+    BBox* other;          // bounding-box slot to zero for a later group (may be null)
     double l_hit, l_miss;
     float lo32, hi32;
     int count_kind;       // 0 = packed (H<<16 | M), 1 = counts are hits, 2 = counts are misses
@@ -265,12 +282,27 @@ __device__ __forceinline__ void ray_finalize_body(const GridDesc& g, const FinAr
     for (int y = y0 + block; y <= y1; y += nblocks)
         for (int x = x0 + threadIdx.x; x <= x1; x += RC_THREADS) {
             const size_t c = (size_t)y * g.nx + x;
-            const uint32_t cn = counts[c];
-            if (cn) {
-                counts[c] = 0;
-                const uint32_t H = count_kind == 0 ? cn >> 16 : (count_kind == 1 ? cn : 0u);
-                const uint32_t M = count_kind == 0 ? cn & 0xffffu : (count_kind == 2 ? cn : 0u);
-                log_odds[c] = apply_counts(log_odds[c], H, M, l_hit, l_miss, lo32, hi32, clip != 0);
+            uint32_t cn[RC_GROUP_MAX];
+            uint32_t any = 0;
+#pragma unroll
+            for (int s = 0; s < RC_GROUP_MAX; ++s) {                 // independent loads first, then the ordered replay
+                cn[s] = s < f.n_grids ? counts[(size_t)s * f.grid_stride + c] : 0u;
+                any |= cn[s];
+            }
+            if (any) {
+                float v = log_odds[c];
+#pragma unroll
+                for (int s = 0; s < RC_GROUP_MAX; ++s)
+                    if (cn[s]) {
+                        counts[(size_t)s * f.grid_stride + c] = 0;
+                        const uint32_t H = count_kind == 0 ? cn[s] >> 16 : (count_kind == 1 ? cn[s] : 0u);
+                        const uint32_t M = count_kind == 0 ? cn[s] & 0xffffu : (count_kind == 2 ? cn[s] : 0u);
+                        v = apply_counts(v, H, M, l_hit, l_miss, lo32, hi32, clip != 0);
+                    } else if (s == 0 && full_clip && clip) {        // untouched by the first scan, but its clip is whole-grid
+                        v = v < lo32 ? lo32 : v;
+                        v = v > hi32 ? hi32 : v;
+                    }
+                log_odds[c] = v;
             } else if (full_clip && clip) {
                 float v = log_odds[c];
                 if (v < lo32) v = lo32;
@@ -291,13 +323,30 @@ __global__ __launch_bounds__(RC_THREADS) void ray_finalize_kernel(GridDesc g, Fi
     ray_finalize_body(g, f, blockIdx.x, gridDim.x);
 }
 
-// One launch of a replay: the first n_count workgroups count scan k into one counter grid while
-// the others finalise scan k-1 from the other counter grid — the two touch disjoint memory, so a
-// replay of S scans is S+1 dependent launches instead of 2S.
+// counting workgroup `block` of a group launch: find its scan, count into that scan's grid
+__device__ __forceinline__ void ray_count_group_body(const GridDesc& g, const double* __restrict__ origins,
+                                                     const double* __restrict__ hits, const ScanGroup& grp,
+                                                     uint32_t* __restrict__ counts, size_t grid_stride, BBox* bbox, int block) {
+    int s = 0;
+#pragma unroll
+    for (int t = 1; t < RC_GROUP_MAX; ++t) s += (t < grp.n && block >= grp.first_block[t]) ? 1 : 0;
+    ray_count_body(g, origins + 2 * (size_t)grp.origin_row[s], hits + 2 * (size_t)grp.hit_row[s], grp.nb[s],
+                   counts + (size_t)s * grid_stride, bbox, RC_DO_HITS | RC_DO_MISS | RC_PACKED, block - grp.first_block[s]);
+}
+
+__global__ __launch_bounds__(RC_THREADS) void ray_count_group_kernel(
+    GridDesc g, const double* __restrict__ origins, const double* __restrict__ hits, ScanGroup grp,
+    uint32_t* __restrict__ counts, size_t grid_stride, BBox* bbox) {
+    ray_count_group_body(g, origins, hits, grp, counts, grid_stride, bbox, blockIdx.x);
+}
+
+// One launch of a replay: the first n_count workgroups count group k into one set of counter grids while the
+// others finalise group k-1 from the other set — the two touch disjoint memory, so a replay of S scans in
+// groups of G is S/G + 1 dependent launches instead of 2S.
 __global__ __launch_bounds__(RC_THREADS) void ray_step_kernel(
-    GridDesc g, const double* __restrict__ origin, const double* __restrict__ hits, int nb,
-    uint32_t* __restrict__ counts, BBox* bbox, int mode, int n_count, FinArgs f) {
-    if ((int)blockIdx.x < n_count) ray_count_body(g, origin, hits, nb, counts, bbox, mode, blockIdx.x);
+    GridDesc g, const double* __restrict__ origins, const double* __restrict__ hits, ScanGroup grp,
+    uint32_t* __restrict__ counts, size_t grid_stride, BBox* bbox, int n_count, FinArgs f) {
+    if ((int)blockIdx.x < n_count) ray_count_group_body(g, origins, hits, grp, counts, grid_stride, bbox, blockIdx.x);
     else ray_finalize_body(g, f, blockIdx.x - n_count, gridDim.x - n_count);
 }
 
@@ -327,10 +376,10 @@ __global__ void bresenham_cells_kernel(const int32_t* __restrict__ segs, const l
 
 }  // namespace icpmi
 
-// two counter grids (scan parity) + three bounding-box slots (scan index mod 3)
+// two sets of RC_GROUP_MAX counter grids (group parity) + three bounding-box slots (group index mod 3)
 extern "C" size_t icpmi_grid_workspace_bytes(int32_t ny, int32_t nx) {
     if (ny <= 0 || nx <= 0) return 0;
-    return 2 * (size_t)ny * (size_t)nx * sizeof(uint32_t) + 256;
+    return 2 * (size_t)icpmi::RC_GROUP_MAX * (size_t)ny * (size_t)nx * sizeof(uint32_t) + 256;
 }
 
 extern "C" int icpmi_world_to_grid(const double* w, int64_t n, double min_w, double resolution, int64_t* out, void* stream) {
@@ -371,45 +420,69 @@ extern "C" int icpmi_grid_update_scans_band(float* log_odds, void* counts_ws, in
     if (ny > RC_COORD_MAX || nx > RC_COORD_MAX || !(resolution > 0.0)) return ICPMI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     const size_t cells = (size_t)ny * (size_t)nx;
-    uint32_t* grid2[2] = {(uint32_t*)counts_ws, (uint32_t*)counts_ws + cells};
-    BBox* slots = (BBox*)((unsigned char*)counts_ws + 2 * cells * sizeof(uint32_t));
+    uint32_t* set2[2] = {(uint32_t*)counts_ws, (uint32_t*)counts_ws + (size_t)RC_GROUP_MAX * cells};
+    BBox* slots = (BBox*)((unsigned char*)counts_ws + 2 * (size_t)RC_GROUP_MAX * cells * sizeof(uint32_t));
+    // every call starts with empty boxes and ends with empty counter grids (each finalise pass zeroes what it
+    // reads), so calls are independent of each other; scan_seq is no longer needed and ignored
+    (void)scan_seq;
+    if (hipMemsetAsync(slots, 0, 3 * sizeof(BBox), st) != hipSuccess) return ICPMI_ERR_HIP;
     GridDesc g{nx, ny, min_x, min_y, resolution, row_begin, row_end};
     FinArgs fin{};
     fin.log_odds = log_odds; fin.l_hit = l_hit; fin.l_miss = l_miss; fin.lo32 = (float)lo; fin.hi32 = (float)hi;
-    bool pending = false;            // a counted scan whose finalisation rides on the next launch
-    int64_t q = scan_seq;            // index of the next non-empty scan (counter grid q&1, box slot q%3)
+    fin.grid_stride = cells; fin.n_grids = 1;
+    bool pending = false;            // a counted group whose finalisation rides on the next launch
+    int64_t q = 0;                   // index of the next group (counter-grid set q&1, box slot q%3)
     int clip_all = full_clip;
-    for (int s = 0; s < n_scans; ++s) {
-        const int nb = hit_off_host[s + 1] - hit_off_host[s];
-        if (nb < 0) return ICPMI_ERR_ARG;
-        if (nb == 0) continue;                                  // mapping.py:113-114: silent no-op, no clip
+    auto blocks_of = [](int nb) {
+        const long waves = (long)((nb + ICPMI_WAVE - 1) / ICPMI_WAVE) * RC_SLOTS;
+        return (int)((waves * ICPMI_WAVE + RC_THREADS - 1) / RC_THREADS);
+    };
+    int s = 0;
+    while (s < n_scans) {
+        const int nb0 = hit_off_host[s + 1] - hit_off_host[s];
+        if (nb0 < 0) return ICPMI_ERR_ARG;
+        if (nb0 == 0) { ++s; continue; }                        // mapping.py:113-114: silent no-op, no clip
         if (!hits) return ICPMI_ERR_ARG;
-        const double* h = hits + 2 * (size_t)hit_off_host[s];
-        const double* o = origins + 2 * (size_t)s;
-        const int groups = (nb + ICPMI_WAVE - 1) / ICPMI_WAVE;
-        const long waves = (long)groups * RC_SLOTS;
-        const int blocks = (int)((waves * ICPMI_WAVE + RC_THREADS - 1) / RC_THREADS);
-        uint32_t* counts = grid2[q & 1];
+        uint32_t* counts = set2[q & 1];
         BBox* cur = slots + (q % 3);
-        if (nb <= 65535) {
-            const int mode = RC_DO_HITS | RC_DO_MISS | RC_PACKED;
-            if (pending) ray_step_kernel<<<blocks + RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, mode, blocks, fin);
-            else ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, mode);
-            // this scan's finalisation: reads its own grid and slot, frees the slot two scans ahead
-            fin.counts = counts; fin.bbox = cur; fin.other = slots + ((q + 2) % 3);
+        if (nb0 <= 65535) {
+            // a group: the following scans too, while they fit a 16-bit counter (empty scans are skipped over)
+            ScanGroup grp{};
+            int t = s;
+            while (t < n_scans && grp.n < RC_GROUP_MAX) {
+                const int nb = hit_off_host[t + 1] - hit_off_host[t];
+                if (nb < 0) return ICPMI_ERR_ARG;
+                if (nb > 65535) break;
+                if (nb > 0) {
+                    grp.nb[grp.n] = nb; grp.origin_row[grp.n] = t; grp.hit_row[grp.n] = hit_off_host[t];
+                    grp.first_block[grp.n + 1] = grp.first_block[grp.n] + blocks_of(nb);
+                    ++grp.n;
+                }
+                ++t;
+            }
+            const int blocks = grp.first_block[grp.n];
+            if (pending) ray_step_kernel<<<blocks + RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, origins, hits, grp, counts, cells, cur, blocks, fin);
+            else ray_count_group_kernel<<<blocks, RC_THREADS, 0, st>>>(g, origins, hits, grp, counts, cells, cur);
+            // this group's finalisation: reads its own grids and slot, frees the slot two groups ahead
+            fin.counts = counts; fin.n_grids = grp.n; fin.bbox = cur; fin.other = slots + ((q + 2) % 3);
             fin.count_kind = 0; fin.clip = 1; fin.full_clip = clip_all;
             pending = true;
+            s = t;
         } else {
             // more beams than a 16-bit counter holds: hits and misses in two rounds, no pipelining
             if (pending) { ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, fin); pending = false; }
+            const double* h = hits + 2 * (size_t)hit_off_host[s];
+            const double* o = origins + 2 * (size_t)s;
+            const int blocks = blocks_of(nb0);
             FinArgs w = fin;
-            w.counts = counts; w.bbox = cur; w.full_clip = 0;
-            ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, RC_DO_HITS);
+            w.counts = counts; w.n_grids = 1; w.bbox = cur; w.full_clip = 0;
+            ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb0, counts, cur, RC_DO_HITS);
             w.other = nullptr; w.count_kind = 1; w.clip = 0;
             ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, w);
-            ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb, counts, cur, RC_DO_MISS);
+            ray_count_kernel<<<blocks, RC_THREADS, 0, st>>>(g, o, h, nb0, counts, cur, RC_DO_MISS);
             w.other = slots + ((q + 2) % 3); w.count_kind = 2; w.clip = 1; w.full_clip = clip_all;
             ray_finalize_kernel<<<RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, w);
+            ++s;
         }
         clip_all = 0;                                           // every cell is inside [lo, hi] after one clipped scan
         ++q;
