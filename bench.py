@@ -37,9 +37,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=8192,
+    ap.add_argument("--pairs-per-gpu", type=int, default=16384,
                     help="scan pairs resident per GPU; the few pairs that run to max_iterations leave most CUs idle at the "
-                         "end of a launch, so throughput grows with the batch (512: 6.8e6 it/s, 8192: 1.33e7 it/s)")
+                         "end of a launch, so throughput grows with the batch (512: 6.8e6, 8192: 1.33e7, 16384: 1.42e7 it/s)")
     ap.add_argument("--pairs-total", type=int, default=0,
                     help="strong scaling: this many pairs in all, split over the GPUs (BASELINE config 5 uses 512)")
     ap.add_argument("--raycast-scans", type=int, default=200)
@@ -130,13 +130,13 @@ def main():
                 "note": "algorithmic bytes = sum over pairs of iterations x (28 N + 16 M), N/M rows after voxel filtering"}
 
     # HBM bytes per launch from the PMC counters cannot be collected from inside this process: they come from the
-    # committed rocprofv3 --pmc passes of this very command (profiles/r01_pmc_traffic_b8192.json), same workload and grid.
+    # committed rocprofv3 --pmc passes of this very command (profiles/r01_pmc_traffic.json), same workload and grid.
     try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic_b8192.json")))["kernels"]
+        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
         key = [k for k in pmc if "icp2_fused_kernel" in k and f"[{B} workgroups]" in k]
         if batch.fast and key:
             roofline["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01_pmc_traffic_b8192.json (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
+            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
     except (OSError, KeyError, ValueError):
         pass
 
