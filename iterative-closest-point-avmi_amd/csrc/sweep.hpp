@@ -91,7 +91,7 @@ __device__ __forceinline__ int sweep_nn2(const double2* sxy, const int32_t* sori
                 const double du = right ? proj(dir, c.x, c.y) - uq : uq - proj(dir, c.x, c.y);
                 if (du > thr) { if (right) hi = m; else lo = -1; }      // everything further out is farther than `second`
                 else {
-                    if (du >= -thr) {
+                    if (true) {   // a candidate before the window costs five flops; testing for it costs a mask branch
                         const double dx = qx - c.x, dy = qy - c.y;
                         double s = 0.0;
                         s += dx * dx;
@@ -156,7 +156,7 @@ __device__ __forceinline__ Top2 sweep_top2(const double2* sxy, const int32_t* so
                 const double du = right ? proj(dir, c.x, c.y) - uq : uq - proj(dir, c.x, c.y);
                 if (du > thr) { if (right) hi = m; else lo = -1; }      // everything further out is farther than the third
                 else {
-                    if (du >= -thr) {
+                    if (true) {   // a candidate before the window costs five flops; testing for it costs a mask branch
                         const double dx = qx - c.x, dy = qy - c.y;
                         double s = 0.0;
                         s += dx * dx;
@@ -212,7 +212,7 @@ __device__ __forceinline__ int sweep_nn(const double2* sxy, const int32_t* sorig
             const double du = proj(dir, c.x, c.y) - uq;
             if (du > thr) hi = m;                               // everything further right is farther still
             else {
-                if (du >= -thr) {
+                if (true) {   // a candidate before the window costs five flops; testing for it costs a mask branch
                     const double dx = qx - c.x, dy = qy - c.y;
                     double s = 0.0;
                     s += dx * dx;
@@ -233,7 +233,7 @@ __device__ __forceinline__ int sweep_nn(const double2* sxy, const int32_t* sorig
             const double du = uq - proj(dir, c.x, c.y);
             if (du > thr) lo = -1;
             else {
-                if (du >= -thr) {
+                if (true) {   // a candidate before the window costs five flops; testing for it costs a mask branch
                     const double dx = qx - c.x, dy = qy - c.y;
                     double s = 0.0;
                     s += dx * dx;
