@@ -453,8 +453,9 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     } while (0)
     // 1 025..2 048 source rows: 1 024 threads x 2 rows (one workgroup per CU) finishes a pair soonest; with thousands
     // of pairs queued, 512 threads x 4 rows (two workgroups per CU: one pair's serial solve and barrier waits overlap
-    // the other's search) moves more pairs per second (7.22 vs 7.70 ms at 8 192 pairs, 2.39 vs 2.34 ms at 2 048).
-    const bool two_per_cu = want == 512 || (want == 0 && n_pairs >= 3072);
+    // the other's search) moves more pairs per second (11.2 vs 14.8 ms at 16 384 pairs, 1.37 vs 1.53 ms at 1 024,
+    // but 1.14 vs 0.97 ms at 512).
+    const bool two_per_cu = want == 512 || (want == 0 && n_pairs >= 1024);
     if (two_per_cu && max_src_n <= 2048) { if (max_src_n <= 1024) ICPMI_ICP2_GO(512, 2); else ICPMI_ICP2_GO(512, 4); }
     else if (want == 1024 || max_src_n > 1024) { if (max_src_n <= 2048) ICPMI_ICP2_GO(1024, 2); else ICPMI_ICP2_GO(1024, 4); }
     else ICPMI_ICP2_GO(512, 2);
