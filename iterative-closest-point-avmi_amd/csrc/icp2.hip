@@ -193,23 +193,22 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                 if (s < S && s * THREADS + tid < N) {
                     // |dx| + |dy| >= the distance between the row and its anchor
                     if ((fabs(px[s] - ax[s]) + fabs(py[s] - ay[s])) * 1.000000001 < budget[s]) {   // match is one of the two kept
-                        const double2 c = sxy[pos[s]];
+                        // straight-line: a missing second candidate stands in as the first (never better), and only an
+                        // exact tie of the two distances takes a branch (to compare the rows)
+                        const int pa = pos[s], pb = pos2[s] >= 0 ? pos2[s] : pos[s];
+                        const double2 c = sxy[pa], e = sxy[pb];
                         const double dx = px[s] - c.x, dy = py[s] - c.y;
-                        double q2 = 0.0;
+                        const double ex = px[s] - e.x, ey = py[s] - e.y;
+                        double q2 = 0.0, w2 = 0.0;
                         q2 += dx * dx;
                         q2 += dy * dy;
-                        if (pos2[s] >= 0) {
-                            const double2 e = sxy[pos2[s]];
-                            const double ex = px[s] - e.x, ey = py[s] - e.y;
-                            double w2 = 0.0;
-                            w2 += ex * ex;
-                            w2 += ey * ey;
-                            if (w2 < q2 || (w2 == q2 && sorig[pos2[s]] < sorig[pos[s]])) {
-                                const int tp = pos[s]; pos[s] = pos2[s]; pos2[s] = tp;
-                                q2 = w2;
-                            }
-                        }
-                        d2[s] = q2;
+                        w2 += ex * ex;
+                        w2 += ey * ey;
+                        bool second_wins = w2 < q2;
+                        if (w2 == q2 && pb != pa) second_wins = sorig[pb] < sorig[pa];
+                        pos[s] = second_wins ? pb : pa;
+                        pos2[s] = pos2[s] >= 0 ? (second_wins ? pa : pb) : -1;
+                        d2[s] = second_wins ? w2 : q2;
                     } else if (it < 2) {
                         // the first steps move every row by more than any budget: plain 1-NN (smallest window)
                         pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], d2[s]);
