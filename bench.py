@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=16384,
                     help="scan pairs resident per GPU; the few pairs that run to max_iterations leave most CUs idle at the "
-                         "end of a launch, so throughput grows with the batch (512: 6.9e6, 8192: 1.53e7, 16384: 1.64e7 it/s)")
+                         "end of a launch, so throughput grows with the batch (512: 7.0e6, 8192: 1.59e7, 16384: 1.69e7 it/s)")
     ap.add_argument("--pairs-total", type=int, default=0,
                     help="strong scaling: this many pairs in all, split over the GPUs (BASELINE config 5 uses 512)")
     ap.add_argument("--raycast-scans", type=int, default=200)
