@@ -199,14 +199,14 @@ int icpmi_bresenham_cells(const int32_t* segs, const int64_t* cell_off, int32_t 
  * hits (world frame, float64).  Per cell the result equals the reference's
  * sequence: H adds of l_hit, then M adds of l_miss, each rounded to float32
  * from a float64 sum, then one clip to [lo, hi] per scan.
- * counts: workspace of icpmi_grid_workspace_bytes(ny, nx) bytes (two sets of 8
+ * counts: workspace of icpmi_grid_workspace_bytes(ny, nx) bytes (two sets of 16
  * uint32 counter grids + bounding-box slots), zeroed once by the caller before
- * first use and owned by this grid afterwards.  With n_scans > 1, up to 8
+ * first use and owned by this grid afterwards.  With n_scans > 1, up to 16
  * consecutive scans are counted in ONE launch, each into its own counter grid,
  * and finalised together in scan order per cell (so the result is the sequential
  * one bit for bit); the count pass of a group shares its launch with the finalise
  * pass of the previous group (the other set of grids): a replay of S scans is
- * about S/8 + 1 launches.  Every call leaves the workspace all zero again.
+ * about S/16 + 1 launches.  Every call leaves the workspace all zero again.
  * scan_seq: ignored (kept for binary compatibility; calls are independent).
  * full_clip != 0 clips every cell of the grid on the first scan (needed only
  * when cells may lie outside [lo, hi] beforehand). */

@@ -239,7 +239,7 @@ __device__ __forceinline__ float apply_counts(float v0, uint32_t H, uint32_t M, 
 // the finalise pass replays the grids in scan order, so the result is the sequential one bit for bit); the
 // launches of a replay drop from one per scan to one per group.
 #ifndef ICPMI_RC_GROUP
-#define ICPMI_RC_GROUP 8
+#define ICPMI_RC_GROUP 16
 #endif
 constexpr int RC_GROUP_MAX = ICPMI_RC_GROUP;
 struct ScanGroup {
