@@ -797,3 +797,28 @@ def test_pose_graph_edge_cases(uicp, capsys):
     with pytest.raises(IndexError):
         pg.add_edge(0, 5, [0, 0, 0])
         pg.optimize()
+
+
+def test_large_batch_uses_two_workgroups_per_cu_and_matches_the_oracle(uicp):
+    """From 1 024 pairs on the launcher runs 512 threads x 4 rows (two workgroups per CU); the voxel filter and the
+    prepare kernel change their occupancy too.  Same results: a sample of the pairs against the oracle, and the
+    whole batch against the same pairs run in small batches (1 024 threads x 2 rows)."""
+    from icpmi import batch, synth
+    B = 1100
+    srcs, tgts = synth.loop_closure_batch(B, seed0=31000)
+    kw = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+    big = batch.IcpBatch(srcs + tgts, np.arange(B), np.arange(B, 2 * B), **kw)
+    big.run()
+    R, t, err, info = big.unpack()
+    for i in range(0, B, 37):
+        Ro, to, eo, io = oracle.icp(srcs[i], tgts[i], 1e-10, 150, 0.04, method="point_to_line", normal_k=12)
+        assert info["iters"][i] == io["iters"] and info["status"][i] == io["status"], i
+        assert rot_err(R[i], t[i], Ro, to) < FRO_TOL, (i, rot_err(R[i], t[i], Ro, to))
+    for lo in range(0, B, 275):
+        idx = np.arange(lo, min(B, lo + 275))
+        small = batch.IcpBatch([srcs[i] for i in idx] + [tgts[i] for i in idx], np.arange(len(idx)),
+                               np.arange(len(idx), 2 * len(idx)), **kw)
+        small.run()
+        Rs, ts, es, infs = small.unpack()
+        assert np.array_equal(infs["iters"], info["iters"][idx])
+        assert max(rot_err(Rs[j], ts[j], R[i], t[i]) for j, i in enumerate(idx)) < 1e-11
