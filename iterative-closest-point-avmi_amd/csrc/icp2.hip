@@ -87,6 +87,9 @@ constexpr int partial_doubles() { return NV * 64; }
 // control block published by wave 0: r (4), t (2), stop flag, mean_p (2), mean_q (2)
 constexpr int CTRL_R = 0, CTRL_T = 4, CTRL_STOP = 6, CTRL_MP = 8, CTRL_MQ = 10, CTRL_DOUBLES = 12;
 
+#ifndef ICP2_PLAIN_ITERS
+#define ICP2_PLAIN_ITERS 2      // iterations that search the plain nearest neighbour before budgets are kept
+#endif
 // THREADS x ICP2_SMAX = most source rows a pair may have on this instantiation
 // TGT_LDS: the prepared target is staged in LDS (<= 4096 points); otherwise it is read in place, through L2
 template <int THREADS, int ICP2_SMAX, bool TGT_LDS>
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                         pos[s] = second_wins ? pb : pa;
                         pos2[s] = pos2[s] >= 0 ? (second_wins ? pa : pb) : -1;
                         d2[s] = second_wins ? w2 : q2;
-                    } else if (it < 2) {
+                    } else if (it < ICP2_PLAIN_ITERS) {
                         // the first steps move every row by more than any budget: plain 1-NN (smallest window)
                         pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], d2[s]);
                     } else {

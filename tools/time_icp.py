@@ -4,6 +4,9 @@ import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "iterative-closest-point-avmi_amd"))
 import numpy as np, torch
+from icpmi import _lib
+if os.environ.get("ICPMI_LIB"):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["ICPMI_LIB"])
 from icpmi import synth
 from icpmi.batch import IcpBatch
 kw = dict(error_threshold=1e-10, max_iterations=int(os.environ.get("MAXIT", "150")), voxel_size=0.04, method="point_to_line", normal_k=12)
