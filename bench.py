@@ -166,6 +166,7 @@ def main():
         line["scan_pair_host_api"] = bench_host_api(srcs[0], tgts[0], not args.no_cpu_baseline)
         if not args.no_raycast:
             line["raycast"] = bench_raycast(torch, synth, args.raycast_scans, not args.no_cpu_baseline)
+        line["pose_graph"] = bench_pose_graph(torch, not args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(srcs, tgts)
     if world > 1 and not args.no_raycast:
@@ -369,6 +370,53 @@ def bench_replay_sharded(torch, dist, synth, n_scans, rank, world, dev, red_dev)
             "bands": bands, "cell_updates": cells, "cells_per_sec": round(cells / dt, 1), "ms_per_replay": round(dt * 1e3, 4),
             "includes": "grid reset + band replay on every rank + all_gather of the bands",
             "grids_identical_on_all_ranks": bool(lo.item() == hi.item())}
+
+
+def bench_pose_graph(torch, with_cpu):
+    """utilities/pose_graph.py:83-134 on an odometry chain of 1 000 poses with 20 loop closures (the shape slam.py
+    builds): every Gauss-Newton iteration in one launch."""
+    from utilities import pose_graph as upg
+    upg.VERBOSE = False
+    rng = np.random.default_rng(0)
+    n, k = 1000, 20
+    th = np.cumsum(rng.normal(0.0, 0.05, n)) + np.linspace(0, 4 * np.pi, n)
+    xy = np.cumsum(np.stack([0.3 * np.cos(th), 0.3 * np.sin(th)], axis=1), axis=0)
+    T = [upg.pose_vec_to_matrix(v) for v in np.column_stack([xy, upg.normalize_angle(th)])]
+    est, edges = [T[0]], []
+    for i in range(1, n):
+        z = upg.relative_transform_vec(T[i - 1], T[i]) + rng.normal(0.0, 0.005, 3)
+        est.append(est[-1] @ upg.pose_vec_to_matrix(z))
+        edges.append((i - 1, i, z, np.eye(3) * rng.uniform(100, 1e4)))
+    for _ in range(k):
+        a_, b_ = int(rng.integers(n // 2, n)), int(rng.integers(0, n // 3))
+        edges.append((a_, b_, upg.relative_transform_vec(T[a_], T[b_]) + rng.normal(0.0, 0.002, 3), np.eye(3) * 2e4))
+    nodes = np.array([upg.pose_matrix_to_vec(t) for t in est])
+
+    def once():
+        pg = upg.PoseGraph2D()
+        for v in nodes:
+            pg.add_node(v)
+        for e in edges:
+            pg.add_edge(*e)
+        t0 = time.perf_counter()
+        pg.optimize()
+        return time.perf_counter() - t0, pg
+
+    once()
+    dt, pg = min((once() for _ in range(3)), key=lambda r: r[0])
+    out = {"workload": f"{n} poses, {n - 1} odometry + {k} closure edges", "ms_per_optimize": round(dt * 1e3, 3),
+           "iterations": pg.last_info["iterations"], "status": pg.last_info["status"],
+           "device_us_per_phase": {a: round(v, 1) for a, v in pg.last_info["phase_us"].items()}}
+    if with_cpu:
+        from oracle import pose_graph as opg
+        ei, ej = np.array([e[0] for e in edges]), np.array([e[1] for e in edges])
+        zz, om = np.array([e[2] for e in edges]), np.array([e[3] for e in edges])
+        t0 = time.perf_counter()
+        ref, it, st, _ = opg.optimize(nodes, ei, ej, zz, om)
+        out["cpu_baseline"] = {"ms_per_optimize": round((time.perf_counter() - t0) * 1e3, 1), "iterations": it,
+                               "kind": "port", "note": "dense NumPy restatement of the reference (LAPACK on all host cores)",
+                               "max_abs_pose_difference": float(np.abs(np.array(pg.nodes) - ref).max())}
+    return out
 
 
 def bench_raycast(torch, synth, n_scans, with_cpu):
