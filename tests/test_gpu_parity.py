@@ -822,3 +822,18 @@ def test_large_batch_uses_two_workgroups_per_cu_and_matches_the_oracle(uicp):
         Rs, ts, es, infs = small.unpack()
         assert np.array_equal(infs["iters"], info["iters"][idx])
         assert max(rot_err(Rs[j], ts[j], R[i], t[i]) for j, i in enumerate(idx)) < 1e-11
+
+
+def test_voxel_all_three_sort_paths(uicp):
+    """voxel.hip sorts (key, row) packed in 32 bits, packed in 64 bits, or as pairs, depending on how many voxels
+    the bounding box holds; all three must give np.unique's rows and order (oracle), bit for bit."""
+    from icpmi import synth
+    a, _ = synth.config2_pair(11)
+    for voxel in (0.04, 0.002, 1e-7):          # ~1.5e5 cells, ~6e7 cells, ~2e16 cells for a 20 m x 12 m room
+        got = uicp.voxel_downsample(a, voxel)
+        ref = oracle.voxel_downsample(a, voxel)
+        assert got.shape == ref.shape and np.array_equal(got, ref), voxel
+    rng = np.random.default_rng(4)
+    cloud3 = rng.uniform(-1, 1, size=(3000, 3))
+    for voxel in (0.2, 0.01, 1e-6):
+        assert np.array_equal(uicp.voxel_downsample(cloud3, voxel), oracle.voxel_downsample(cloud3, voxel)), voxel
