@@ -837,3 +837,29 @@ def test_voxel_all_three_sort_paths(uicp):
     cloud3 = rng.uniform(-1, 1, size=(3000, 3))
     for voxel in (0.2, 0.01, 1e-6):
         assert np.array_equal(uicp.voxel_downsample(cloud3, voxel), oracle.voxel_downsample(cloud3, voxel)), voxel
+
+
+def test_replay_groups_with_wide_and_empty_scans(umap):
+    """A replay whose groups of 16 scans are interrupted by a scan with more beams than a 16-bit counter holds (two-round
+    path, flushes the pending group) and by empty scans (skipped, not clipped): equal to the scans applied one by one."""
+    from icpmi import synth
+    rng = np.random.default_rng(17)
+    segs = synth.room_segments()
+    poses = [(0.2 * i - 3.0, 0.1 * i - 1.0, 0.2 * i) for i in range(40)]
+    hits = [synth.to_world(synth.scan(p, 700 + i, segs=segs)[::2], p) for i, p in enumerate(poses)]
+    hits[21] = rng.uniform(-9.5, 9.5, size=(70000, 2)) * np.array([1.0, 0.6])       # wide scan
+    hits[27] = np.empty((0, 2))
+    hits[0] = np.empty((0, 2))
+    org = np.array([[p[0], p[1]] for p in poses])
+    kw = dict(resolution=0.05, p_hit=0.7, p_miss=0.45, log_odds_min=-4.0, log_odds_max=6.0)
+    g = umap.OccupancyGrid2D(-11.0, 11.0, -7.0, 7.0, **kw)
+    g.update_scans(org, hits)
+    ref = np.zeros((g.ny, g.nx), dtype=np.float32)
+    for o, h in zip(org, hits):
+        if len(h):
+            oracle.grid_update_scan(ref, g.min_x, g.min_y, 0.05, o, h, g.l_hit, g.l_miss, -4.0, 6.0)
+    assert np.array_equal(g.log_odds, ref)
+    one = umap.OccupancyGrid2D(-11.0, 11.0, -7.0, 7.0, **kw)
+    for o, h in zip(org, hits):
+        one.update_scan(o, h)
+    assert np.array_equal(one.log_odds, ref)
