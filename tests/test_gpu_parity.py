@@ -863,3 +863,24 @@ def test_replay_groups_with_wide_and_empty_scans(umap):
     for o, h in zip(org, hits):
         one.update_scan(o, h)
     assert np.array_equal(one.log_odds, ref)
+
+
+def test_pose_graph_python_index_semantics(uicp):
+    """The reference indexes `self.nodes[i]` with whatever the caller passed: -1 is the last node."""
+    from utilities import pose_graph as upg
+    rng = np.random.default_rng(3)
+    nodes = np.cumsum(rng.normal(0.3, 0.05, size=(9, 3)) * np.array([1.0, 0.3, 0.1]), axis=0)
+
+    def build(last):
+        pg = upg.PoseGraph2D()
+        for v in nodes:
+            pg.add_node(v)
+        for k in range(1, 9):
+            pg.add_edge(k - 1, k, nodes[k] - nodes[k - 1] + rng.normal(0, 1e-3, 3) * 0, np.eye(3) * 50.0)
+        pg.add_edge(last, 0, [-2.0, -0.5, -0.6], np.eye(3) * 200.0)
+        pg.optimize()
+        return np.array(pg.nodes), pg.total_error()
+
+    a, ea = build(8)
+    b, eb = build(-1)
+    assert np.array_equal(a, b) and ea == eb
