@@ -3,12 +3,14 @@
 ``PoseGraph2D`` run on the MI355X through libicpmi.so.  ``feature_based_alignment``
 (off by default in the reference, unseeded RANSAC) is outside the accelerated path
 and raises NotImplementedError."""
-from .icp import ICP, voxel_downsample  # noqa: F401
-from .features import feature_based_alignment, rotation_search  # noqa: F401
-from .mapping import OccupancyGrid2D  # noqa: F401
-from .pose_graph import (  # noqa: F401
-    PoseGraph2D,
-    pose_matrix_to_vec,
-    pose_vec_to_matrix,
-    relative_transform_vec,
-)
+from . import features, icp, mapping, pose_graph  # noqa: F401
+
+ICP, voxel_downsample = icp.ICP, icp.voxel_downsample
+rotation_search, feature_based_alignment = features.rotation_search, features.feature_based_alignment
+OccupancyGrid2D = mapping.OccupancyGrid2D
+PoseGraph2D = pose_graph.PoseGraph2D
+pose_matrix_to_vec, pose_vec_to_matrix = pose_graph.pose_matrix_to_vec, pose_graph.pose_vec_to_matrix
+relative_transform_vec = pose_graph.relative_transform_vec
+
+__all__ = ["ICP", "voxel_downsample", "rotation_search", "feature_based_alignment", "OccupancyGrid2D", "PoseGraph2D",
+           "pose_matrix_to_vec", "pose_vec_to_matrix", "relative_transform_vec"]
