@@ -6,9 +6,12 @@ pairs resident in HBM: per pair exactly what the reference's ``ICP()`` call does
 (voxel filter of both scans, target normals, point-to-line ICP to convergence
 with the config.yaml parameters of BASELINE config 2), ``--pairs-per-gpu`` pairs
 per GPU (the batched loop-closure shape of config 5), followed by the all_gather
-of the result records.  Weak scaling: every rank owns its own pairs.
+of the result records.  The main line is weak scaling (every rank owns its own
+pairs); BASELINE config 5 as written — 512 candidate pairs in all — rides on the
+same line as ``config5_512`` (one GPU) / ``strong_512`` (N GPUs, 512/N pairs each).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 --steps 20 --warmup 3      # starts 8 child ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
            --master-port 29500 bench.py --gpus 8 --steps 20 --warmup 3
 
@@ -32,21 +35,156 @@ FP64_VALU_PEAK_TOPS = 39.3       # 78.6 TFLOP/s vector FP64 counts an FMA as 2; 
 ICP_KW = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_command(n_gpus, argv, port):
+    """The child command of a plain `python bench.py --gpus N` (N > 1): one rank per GPU under torch.distributed.run."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus, argv):
+    """Started without WORLD_SIZE but asked for several GPUs: start the ranks as CHILD processes — before this process
+    has imported torch or touched the GPU, and never by exec — relay rank 0's JSON line and return the children's code."""
+    import subprocess
+    cmd = launch_command(n_gpus, argv, free_port())
+    if os.environ.get("ICPMI_BENCH_DRYLAUNCH") == "1":          # CPU test hook: show the decision, start nothing
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL needs it on this host driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    for ln in proc.stdout:                                       # the JSON line to stdout, everything else to stderr
+        (sys.stdout if ln.lstrip().startswith('{"metric"') else sys.stderr).write(ln)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def csrc_signature():
+    """sha256 over the kernel sources the loaded library was built from (names + bytes, sorted): what a committed PMC
+    summary must carry to be quoted as this build's `roofline.traffic`."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "iterative-closest-point-avmi_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")) or f == "Makefile":
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_TRAFFIC = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+
+
+def pmc_traffic(kernel_substr, workgroups):
+    """(bytes per launch, source note) from the committed rocprofv3 --pmc summary, or (None, why) when that summary was
+    collected on other kernel sources than the ones this library was built from (a stale figure is refused)."""
+    try:
+        doc = json.load(open(PMC_TRAFFIC))
+    except (OSError, ValueError):
+        return None, "no committed PMC summary"
+    if doc.get("csrc_sha256") != csrc_signature():
+        return None, (f"profiles/{os.path.basename(PMC_TRAFFIC)} was collected on csrc {doc.get('csrc_sha256')}, this build is "
+                      f"{csrc_signature()}: stale, not quoted")
+    key = [k for k in doc.get("kernels", {}) if kernel_substr in k and f"[{workgroups} workgroups]" in k]
+    if not key:
+        return None, "kernel/grid not in the committed PMC summary"
+    return doc["kernels"][key[0]]["hbm_bytes_per_launch"], (f"profiles/{os.path.basename(PMC_TRAFFIC)} (2 x FETCH_SIZE + "
+                                                            "WRITE_SIZE, KiB -> bytes; same csrc signature)")
+
+
+class Leg:
+    """One timed leg of the hot path: a resident IcpBatch of B pairs per rank, K steps, barrier + synchronize on both
+    sides, MAX over ranks; every step = voxel x2 + prepare + fused ICP + (world > 1) the all_gather of the results."""
+
+    def __init__(self, torch, dist, IcpBatch, gather_results, synth, B, rank, world, red_dev, seed0):
+        self.torch, self.dist, self.gather, self.B, self.rank, self.world, self.red_dev = torch, dist, gather_results, B, rank, world, red_dev
+        self.srcs, self.tgts = synth.loop_closure_batch(B, seed0=seed0 + 100003 * rank)
+        self.batch = IcpBatch(self.srcs + self.tgts, np.arange(B), np.arange(B, 2 * B), **ICP_KW)
+        self.n_total = B * world
+
+    def step(self, ev=None):
+        res = self.batch.run(events=ev)
+        return self.gather(res[:self.B], self.n_total, self.rank, self.world) if self.world > 1 else res
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, steps, warmup):
+        torch = self.torch
+        for _ in range(warmup):
+            self.step()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        self.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            out = self.step(events[k])
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=self.red_dev)
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        from icpmi import _lib
+        res = out.cpu().numpy()                               # all pairs of all ranks (gathered) or the local batch
+        self.iters_per_step = float(res[:self.n_total, _lib.RES_ITERS].sum())
+        self.elapsed, self.steps = elapsed, steps
+        self.value = self.iters_per_step * steps / elapsed
+        self.k_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+        return self
+
+    def roofline(self):
+        """Dominant kernel (fused ICP) of rank 0's launch: algorithmic bytes / live HIP-event time."""
+        from icpmi import _lib
+        b, B = self.batch, self.B
+        local = b.results.cpu().numpy()[:B]
+        cnt = b.vox.cnt.cpu().numpy()
+        self.N = cnt[b.pair_src_host].astype(np.float64)
+        self.M = cnt[b.pair_tgt_host].astype(np.float64)
+        it = local[:, _lib.RES_ITERS]
+        alg_bytes = float((it * (28.0 * self.N + 16.0 * self.M)).sum())   # SURVEY §8d: 16N+16M read + 12N written per pair-iteration
+        achieved = alg_bytes / (self.k_ms * 1e-3) / 1e9
+        name = "icp2_fused_kernel (fused ICP, sorted-sweep search)" if b.fast else "icp_fused_kernel"
+        r = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms": round(self.k_ms, 4),
+             "algorithmic_bytes_per_launch": alg_bytes, "pair_iterations_per_launch": float(it.sum()),
+             "note": "algorithmic bytes = sum over pairs of iterations x (28 N + 16 M), N/M rows after voxel filtering; the "
+                     "kernel keeps a pair on chip for all its iterations, so it is bound by its instruction stream "
+                     "(VALU + divergence), not by HBM: see traffic and profiles/r02_pmc_instruction_mix.json"}
+        if b.fast:
+            r["traffic"], r["traffic_source"] = pmc_traffic("icp2_", B)
+            if r["traffic"]:
+                r["traffic_GBps"] = round(r["traffic"] / (self.k_ms * 1e-3) / 1e9, 1)
+        return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-gpu", type=int, default=16384,
-                    help="scan pairs resident per GPU; the few pairs that run to max_iterations leave most CUs idle at the "
-                         "end of a launch, so throughput grows with the batch (512: 7.0e6, 8192: 1.59e7, 16384: 1.69e7 it/s)")
+                    help="scan pairs resident per GPU (weak scaling); the few pairs that run to max_iterations leave most "
+                         "CUs idle at the end of a launch, so throughput grows with the batch")
     ap.add_argument("--pairs-total", type=int, default=0,
-                    help="strong scaling: this many pairs in all, split over the GPUs (BASELINE config 5 uses 512)")
+                    help="strong scaling as the MAIN line: this many pairs in all, split over the GPUs (BASELINE config 5 "
+                         "uses 512; the default line carries that case as config5_512 / strong_512 anyway)")
     ap.add_argument("--raycast-scans", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-raycast", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="only the main line (no single-pair, submap, ... legs)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -59,7 +197,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     # ICPMI_BENCH_REHEARSE=1: every rank on cuda:0 with gloo (collectives staged through the host) — only to
@@ -70,88 +208,55 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = torch.device("cpu") if rehearse else dev       # where the scalars of an all_reduce live
+    backend = None
     if world > 1:
+        backend = "gloo" if rehearse else "nccl"
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    # ── workload: distinct pairs per rank, inputs resident in HBM before timing ──
+    # ── main line: distinct pairs per rank, inputs resident in HBM before timing ──
     B = args.pairs_per_gpu
     if args.pairs_total:
         if args.pairs_total % world:
             raise SystemExit("--pairs-total must be a multiple of the number of GPUs")
         B = args.pairs_total // world
-    srcs, tgts = synth.loop_closure_batch(B, seed0=1000 + 100003 * rank)
-    batch = IcpBatch(srcs + tgts, np.arange(B), np.arange(B, 2 * B), **ICP_KW)
-    n_total = B * world
+    mk = lambda b, seed0: Leg(torch, dist, IcpBatch, gather_results, synth, b, rank, world, red_dev, seed0)
+    leg = mk(B, 1000).run(args.steps, args.warmup)
+    roofline = leg.roofline()
+    srcs, tgts = leg.srcs, leg.tgts
 
-    def step(ev=None):
-        res = batch.run(events=ev)
-        return gather_results(res[:B], n_total, rank, world) if world > 1 else res
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        out = step(events[k])
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    res = out.cpu().numpy()                                   # all pairs of all ranks (gathered) or the local batch
-    iters_per_step = float(res[:, _lib.RES_ITERS].sum())
-    value = iters_per_step * args.steps / elapsed
-
-    # ── roofline of the dominant kernel (fused ICP), rank 0's launch ────────────
-    local = batch.results.cpu().numpy()[:B]
-    cnt = batch.vox.cnt.cpu().numpy()
-    N = cnt[batch.pair_src_host].astype(np.float64)
-    M = cnt[batch.pair_tgt_host].astype(np.float64)
-    it = local[:, _lib.RES_ITERS]
-    alg_bytes = float((it * (28.0 * N + 16.0 * M)).sum())    # 16N+16M read + 12N written per pair-iteration
-    k_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
-    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-    roofline = {"kernel": "icp2_fused_kernel (fused ICP, sorted-sweep search)" if batch.fast else "icp_fused_kernel",
-                "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                "pair_iterations_per_launch": float(it.sum()),
-                "note": "algorithmic bytes = sum over pairs of iterations x (28 N + 16 M), N/M rows after voxel filtering"}
-
-    # HBM bytes per launch from the PMC counters cannot be collected from inside this process: they come from the
-    # committed rocprofv3 --pmc passes of this very command (profiles/r01_pmc_traffic.json), same workload and grid.
-    try:
-        pmc = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")))["kernels"]
-        key = [k for k in pmc if "icp2_fused_kernel" in k and f"[{B} workgroups]" in k]
-        if batch.fast and key:
-            roofline["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"
-    except (OSError, KeyError, ValueError):
-        pass
-
-    line = {"metric": "icp_iterations_per_sec", "value": round(value, 1), "unit": "iterations/s",
+    line = {"metric": "icp_iterations_per_sec", "value": round(leg.value, 1), "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "ms_per_step": round(leg.elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "strong" if args.pairs_total else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "config 2 scan pairs (2048-beam room scans, point_to_line ICP, voxel 0.04, "
-                                   "normal_k 12, thr 1e-10) batched as in config 5",
-                       "pairs_per_gpu": B, "pairs_total": n_total,
-                       "mean_points_after_voxel": [round(float(N.mean()), 1), round(float(M.mean()), 1)],
-                       "iterations_per_step": iters_per_step, "parallelism": f"pairs sharded over {world} GPU(s)",
+                                   "normal_k 12, thr 1e-10) batched as in config 5; throughput batch of "
+                                   f"{B} resident pairs per GPU (config 5 itself, 512 pairs: see config5_512 / strong_512)",
+                       "pairs_per_gpu": B, "pairs_total": leg.n_total,
+                       "mean_points_after_voxel": [round(float(leg.N.mean()), 1), round(float(leg.M.mean()), 1)],
+                       "iterations_per_step": leg.iters_per_step, "parallelism": f"pairs sharded over {world} GPU(s)",
                        "includes": "voxel_downsample x2 + estimate_normals_2d + ICP loop + result all_gather"},
             "roofline": roofline}
+    if world > 1:
+        line["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                              "library": "RCCL over xGMI" if backend == "nccl" else "gloo (rehearsal)",
+                              "what": "one all_gather_into_tensor of 128-B result records per step, inside the timed region"}
+
+    # ── BASELINE config 5 as written: 512 candidate pairs in all (one GPU: one batch; N GPUs: 512/N pairs each +
+    #    the all_gather) — strong scaling, same K steps, same barriers ──
+    if not args.pairs_total and 512 % world == 0 and not (args.no_extras and world == 1):
+        c5 = mk(512 // world, 5000).run(args.steps, args.warmup)
+        r5 = c5.roofline()
+        obj = {"workload": "BASELINE config 5: 512 candidate scan pairs in all, point_to_line ICP as config 2",
+               "pairs_total": 512, "pairs_per_gpu": 512 // world, "value": round(c5.value, 1), "unit": "iterations/s",
+               "ms_per_step": round(c5.elapsed / args.steps * 1e3, 4), "iterations_per_step": c5.iters_per_step,
+               "scaling": "strong", "roofline": r5}
+        line["config5_512" if world == 1 else "strong_512"] = obj
+        if world > 1:
+            line["weak"] = {"pairs_per_gpu": B, "value": line["value"], "ms_per_step": line["ms_per_step"]}
 
     if rank == 0 and world == 1 and not args.no_extras:
         # single-pair latency (config 2 exactly as the reference calls it, one pair)
@@ -161,7 +266,7 @@ def main():
         line["single_pair"] = {"ms_per_icp": round(lat * 1e3, 4), "iterations": it1,
                                "iterations_per_sec": round(it1 / lat, 1)}
         line["pipelined"] = bench_pipelined(torch, IcpBatch, _lib, srcs, tgts, max(args.steps, 8))
-        line["nn_exhaustive"] = bench_nn_exhaustive(torch, batch, _lib)
+        line["nn_exhaustive"] = bench_nn_exhaustive(torch, leg.batch, _lib)
         line["submap"] = bench_submap(torch, synth, not args.no_cpu_baseline)
         line["scan_pair_host_api"] = bench_host_api(srcs[0], tgts[0], not args.no_cpu_baseline)
         if not args.no_raycast:

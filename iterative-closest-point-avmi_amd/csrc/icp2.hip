@@ -20,6 +20,7 @@
 //
 // Pairs that do not fit (more than 4 rows per thread, target larger than the
 // LDS copy, 3-D) run on the exhaustive kernel of icp.hip.
+#include <cstdio>
 #include <cstdlib>
 
 #include "linalg.hpp"
@@ -58,6 +59,8 @@ struct Icp2Args {
     int max_iterations;
     int method;
     int has_init;
+    int n_lo;                 // this launch registers the pairs whose source has more than n_lo rows (-1: all) ...
+    int skip_over;            // ... and, if set, leaves pairs beyond its THREADS x SMAX rows to a second launch
 };
 
 // Two-level workgroup sum that keeps the many waves cheap: every wave only sums
@@ -90,10 +93,13 @@ constexpr int CTRL_R = 0, CTRL_T = 4, CTRL_STOP = 6, CTRL_MP = 8, CTRL_MQ = 10, 
 #ifndef ICP2_PLAIN_ITERS
 #define ICP2_PLAIN_ITERS 2      // iterations that search the plain nearest neighbour before budgets are kept
 #endif
+#ifndef ICP2_CENTRED_ITERS
+#define ICP2_CENTRED_ITERS 3    // iterations whose top-two search starts at the row's own projection; later ones walk from the kept match
+#endif
 // THREADS x ICP2_SMAX = most source rows a pair may have on this instantiation
 // TGT_LDS: the prepared target is staged in LDS (<= 4096 points); otherwise it is read in place, through L2
 template <int THREADS, int ICP2_SMAX, bool TGT_LDS>
-__global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   // 4 waves/SIMD: 2 x 512 or 1 x 1024 per CU
+__global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_kernel(Icp2Args a) {   // waves/SIMD: 2 x 512, 2 x 768 or 1 x 1024 per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ double redA[partial_doubles<11>()];     // normal equations (10) / centroid sums (5) + carried squared error
     __shared__ double redB[partial_doubles<4>()];      // cross-covariance
@@ -111,6 +117,10 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
     const double* src = a.pts + (size_t)a.off[sc] * 2;
     double* res = a.results + (size_t)b * ICPMI_RES_DOUBLES;
     const int dir = a.g_dir[tc];
+    // The voxel filter leaves the row counts on the device, so the launcher sizes the rows per thread for the usual
+    // case and sends the (rare) larger clouds to a second launch of a wider shape: each pair is registered by
+    // exactly one of the two (uniform per workgroup, before any barrier).
+    if (N <= a.n_lo || (a.skip_over && N > THREADS * ICP2_SMAX)) return;
 
     // two instantiations, each sees ONE address space behind these pointers
     double2* lds_xy = reinterpret_cast<double2*>(dyn);
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                 if (use_p2l) lds_nrm[i] = gn[i];
             }
         // moving source rows in registers: row n = s*THREADS + tid
-        double px[ICP2_SMAX], py[ICP2_SMAX], d2[ICP2_SMAX];
+        double px[ICP2_SMAX], py[ICP2_SMAX];
         int pos[ICP2_SMAX];
         // Movement budget of each row's match.  A search returns the two nearest
         // target points and the distance d3 of the third.  While the row is
@@ -156,15 +166,19 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
         // rounding, equal distances fall back on the row rule or on a new search.
         // Net displacement, so a pair that oscillates in a limit cycle (the usual
         // reason for running to max_iterations) stops searching too.
-        double ax[ICP2_SMAX], ay[ICP2_SMAX], budget[ICP2_SMAX];
+        // Anchor and budget are kept in SINGLE precision (registers: four rows per
+        // thread must not spill): the budget is lowered by the rounding of the
+        // anchor (2^-24 of each coordinate) and rounded down, so the test stays
+        // conservative — it can only send a row to a search it did not need.
+        float ax[ICP2_SMAX], ay[ICP2_SMAX], budget[ICP2_SMAX];
         int pos2[ICP2_SMAX];
 #pragma unroll
-        for (int s = 0; s < ICP2_SMAX; ++s) { ax[s] = 0.0; ay[s] = 0.0; budget[s] = -1.0; pos2[s] = -1; }
+        for (int s = 0; s < ICP2_SMAX; ++s) { ax[s] = 0.0f; ay[s] = 0.0f; budget[s] = -1.0f; pos2[s] = -1; }
         const int S = (N + THREADS - 1) / THREADS;
 #pragma unroll
         for (int s = 0; s < ICP2_SMAX; ++s) {
             const int n = s * THREADS + tid;
-            px[s] = 0.0; py[s] = 0.0; d2[s] = 0.0; pos[s] = -1;          // -1: no previous match yet
+            px[s] = 0.0; py[s] = 0.0; pos[s] = -1;                       // -1: no previous match yet
             if (n < N) {
                 const double x = src[2 * n], y = src[2 * n + 1];
                 if (a.has_init) {                           // source @ R_init.T + t_init
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
             for (int s = 0; s < ICP2_SMAX; ++s)
                 if (s < S && s * THREADS + tid < N) {
                     // |dx| + |dy| >= the distance between the row and its anchor
-                    if ((fabs(px[s] - ax[s]) + fabs(py[s] - ay[s])) * 1.000000001 < budget[s]) {   // match is one of the two kept
+                    if ((fabs(px[s] - (double)ax[s]) + fabs(py[s] - (double)ay[s])) * 1.000000001 < (double)budget[s]) {   // match is one of the two kept
                         // straight-line: a missing second candidate stands in as the first (never better), and only an
                         // exact tie of the two distances takes a branch (to compare the rows)
                         const int pa = pos[s], pb = pos2[s] >= 0 ? pos2[s] : pos[s];
@@ -211,17 +225,21 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                         if (w2 == q2 && pb != pa) second_wins = sorig[pb] < sorig[pa];
                         pos[s] = second_wins ? pb : pa;
                         pos2[s] = pos2[s] >= 0 ? (second_wins ? pa : pb) : -1;
-                        d2[s] = second_wins ? w2 : q2;
                     } else if (it < ICP2_PLAIN_ITERS) {
-                        // the first steps move every row by more than any budget: plain 1-NN (smallest window)
-                        pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], d2[s]);
+                        // the first steps move every row by more than any budget: plain 1-NN (smallest window), started at
+                        // the row's own projection — the previous match only seeds the bound (it lies a whole step away)
+                        double d2s;
+                        pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], true, d2s);
                     } else {
-                        const Top2 t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s]);
-                        pos[s] = t2.p1; pos2[s] = t2.p2; d2[s] = t2.s1;
+                        const Top2 t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], it < ICP2_CENTRED_ITERS);
+                        pos[s] = t2.p1; pos2[s] = t2.p2;
                         const double d1 = sqrt(t2.s1), d3 = sqrt(t2.s3);
-                        budget[s] = t2.s3 < __builtin_inf() ? (d3 - d1) * 0.4999999995 - 1e-13 * (d3 + d1)
-                                                             : __builtin_inf();
-                        ax[s] = px[s]; ay[s] = py[s];
+                        // minus the rounding of the single-precision anchor; rounded down
+                        const double bud = (d3 - d1) * 0.4999999995 - 1e-13 * (d3 + d1) - 1.3e-7 * (fabs(px[s]) + fabs(py[s]));
+                        float bf = (float)bud;
+                        bf = bf - fabsf(bf) * 1e-6f;
+                        budget[s] = t2.s3 < __builtin_inf() ? bf : __builtin_inff();
+                        ax[s] = (float)px[s]; ay[s] = (float)py[s];
 #ifdef ICPMI_DIAG
                         atomicAdd(&res[8], 1.0);             // diag: number of searches run by this pair
 #endif
@@ -234,15 +252,11 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
 #ifdef ICPMI_DIAG
             unsigned long long c2 = 0;
 #endif
+            // rows that take part in the solve: all valid rows, or those within max_corr_dist of their match
+            // (icp.py:184-185: nn_dists**2 < max_corr_dist**2, the distance squared again after its root)
             bool in[ICP2_SMAX];
 #pragma unroll
-            for (int s = 0; s < ICP2_SMAX; ++s) {
-                in[s] = s < S && s * THREADS + tid < N;
-                if (in[s] && has_corr) {                                          // icp.py:184-185
-                    const double dist = sqrt(d2[s]);
-                    in[s] = dist * dist < max_corr_sq;
-                }
-            }
+            for (int s = 0; s < ICP2_SMAX; ++s) in[s] = s < S && s * THREADS + tid < N;
             if (use_p2l) {
                 // ── point-to-line normal equations, icp.py:88-104, + carried error ─
                 double acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -251,6 +265,13 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                     if (!in[s]) continue;
                     const double2 q = sxy[pos[s]], nm = snrm[pos[s]];
                     const double dx = px[s] - q.x, dy = py[s] - q.y;
+                    if (has_corr) {                                   // the search's squared distance, recomputed bit for bit
+                        double s2 = 0.0;
+                        s2 += dx * dx;
+                        s2 += dy * dy;
+                        const double dist = sqrt(s2);
+                        if (!(dist * dist < max_corr_sq)) continue;
+                    }
                     const double c = nm.y * px[s] - nm.x * py[s];
                     const double bi = -(nm.x * dx + nm.y * dy);
                     acc[0] += c * c;       acc[1] += c * nm.x;    acc[2] += c * nm.y;
@@ -312,6 +333,15 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                 for (int s = 0; s < ICP2_SMAX; ++s) {
                     if (!in[s]) continue;
                     const double2 q = sxy[pos[s]];
+                    if (has_corr) {                                   // the search's squared distance, recomputed bit for bit
+                        const double dx = px[s] - q.x, dy = py[s] - q.y;
+                        double s2 = 0.0;
+                        s2 += dx * dx;
+                        s2 += dy * dy;
+                        const double dist = sqrt(s2);
+                        in[s] = dist * dist < max_corr_sq;
+                        if (!in[s]) continue;
+                    }
                     m[0] += px[s]; m[1] += py[s]; m[2] += q.x; m[3] += q.y; m[4] += 1.0;
                 }
                 m[5] = e_part;
@@ -441,26 +471,47 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     a.max_iterations = p->max_iterations; a.method = p->method; a.has_init = p->has_init;
     const bool in_lds = max_tgt_n <= 4096;
     const size_t lds = in_lds ? (size_t)cap * 36 : 0;
-    // Workgroup shape by source size (rows per thread bounded by the instantiation).  ICPMI_ICP2_THREADS
-    // (512 / 1024) overrides the thread count for experiments.
-    const char* env = getenv("ICPMI_ICP2_THREADS");
-    const int want = env ? atoi(env) : 0;
-#define ICPMI_ICP2_GO(T, SM)                                                                                                     \
-    do { if (in_lds) ICPMI_ICP2_GO2(T, SM, true); else ICPMI_ICP2_GO2(T, SM, false); } while (0)
-#define ICPMI_ICP2_GO2(T, SM, L)                                                                                                 \
+    // Workgroup shape by source size (rows per thread bounded by the instantiation).  ICPMI_ICP2_SHAPE = "TxS"
+    // (threads x rows per thread, one of the instantiations below) overrides the choice for experiments.
+    int T = 0, SM = 0;
+    if (const char* env = getenv("ICPMI_ICP2_SHAPE")) {
+        if (sscanf(env, "%dx%d", &T, &SM) != 2) { T = 0; SM = 0; }
+    }
+#define ICPMI_ICP2_GO(TT, SS)                                                                                                    \
+    do { if (in_lds) ICPMI_ICP2_GO2(TT, SS, true); else ICPMI_ICP2_GO2(TT, SS, false); } while (0)
+#define ICPMI_ICP2_GO2(TT, SS, L)                                                                                                \
     do {                                                                                                                         \
-        if (hipFuncSetAttribute((const void*)icp2_fused_kernel<T, SM, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=  \
+        if (hipFuncSetAttribute((const void*)icp2_fused_kernel<TT, SS, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != \
             hipSuccess) return ICPMI_ERR_HIP;                                                                                    \
-        icp2_fused_kernel<T, SM, L><<<n_pairs, T, lds, st>>>(a);                                                                    \
+        icp2_fused_kernel<TT, SS, L><<<n_pairs, TT, lds, st>>>(a);                                                                 \
     } while (0)
-    // 1 025..2 048 source rows: 1 024 threads x 2 rows (one workgroup per CU) finishes a pair soonest; with thousands
-    // of pairs queued, 512 threads x 4 rows (two workgroups per CU: one pair's serial solve and barrier waits overlap
-    // the other's search) moves more pairs per second (11.2 vs 14.8 ms at 16 384 pairs, 1.37 vs 1.53 ms at 1 024,
-    // but 1.14 vs 0.97 ms at 512).
-    const bool two_per_cu = want == 512 || (want == 0 && n_pairs >= 1024);
-    if (two_per_cu && max_src_n <= 2048) { if (max_src_n <= 1024) ICPMI_ICP2_GO(512, 2); else ICPMI_ICP2_GO(512, 4); }
-    else if (want == 1024 || max_src_n > 1024) { if (max_src_n <= 2048) ICPMI_ICP2_GO(1024, 2); else ICPMI_ICP2_GO(1024, 4); }
-    else ICPMI_ICP2_GO(512, 2);
+    a.n_lo = -1; a.skip_over = 0;
+    int T2 = 0, SM2 = 0;                // second launch for the pairs the first shape cannot hold
+    if (T == 0) {
+        // A voxel-filtered 2 048-beam scan keeps ~1 400 rows: 512 threads x 3 rows, two workgroups per CU — one pair's
+        // serial solve and barrier waits overlap the other's search.  Sources that keep more than 1 536 rows go to a
+        // second launch (1 024 threads).  With few pairs (less than two per CU) 1 024 threads x 2 rows finish a pair
+        // soonest.
+        const bool many = n_pairs >= 1024;
+        if (max_src_n <= 1024) { T = 512; SM = 2; }
+        else if (many) { T = 512; SM = 3; }
+        else if (max_src_n <= 2048) { T = 1024; SM = 2; }
+        else { T = 1024; SM = 4; }
+    }
+    if (T * SM < max_src_n) { T2 = 1024; SM2 = max_src_n <= 2048 ? 2 : 4; a.skip_over = 1; }
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            if (!T2) break;
+            a.n_lo = T * SM; a.skip_over = 0; T = T2; SM = SM2;
+        }
+        if (T == 512 && SM == 2) ICPMI_ICP2_GO(512, 2);
+        else if (T == 512 && SM == 3) ICPMI_ICP2_GO(512, 3);
+        else if (T == 512 && SM == 4) ICPMI_ICP2_GO(512, 4);
+        else if (T == 768 && SM == 2) ICPMI_ICP2_GO(768, 2);
+        else if (T == 1024 && SM == 2) ICPMI_ICP2_GO(1024, 2);
+        else if (T == 1024 && SM == 4) ICPMI_ICP2_GO(1024, 4);
+        else return ICPMI_ERR_ARG;
+    }
 #undef ICPMI_ICP2_GO
 #undef ICPMI_ICP2_GO2
     ICPMI_LAUNCH_CHECK();

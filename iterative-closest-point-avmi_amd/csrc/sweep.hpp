@@ -49,13 +49,18 @@ __device__ __forceinline__ int sweep_lower_bound(const double2* sxy, int m, int 
 }
 
 // Half-width of the projection window that can still hold a winner: a candidate
-// with |u(q) - u(c)| > prune_width(...) has squared distance > best.  One sqrt
-// per improvement of `best` buys a two-instruction test per candidate.  The
-// factors cover the rounding of the sqrt, of du*du and (diagonals) of x +- y;
-// uabs = max |u| over the target.  Conservative: never skips a possible winner.
+// with |u(q) - u(c)| > prune_width(...) has squared distance > best.  One root
+// per improvement of `best` buys a two-instruction test per candidate; the root
+// is a SINGLE-precision one rounded up (a float64 sqrt is ~30 instructions, and
+// a bound improves several times per search): (float)best is within 2^-24 of
+// best, v_sqrt_f32 within 1 ulp, so root * 1.000001f exceeds the true root for
+// every normal float; +1e-18 covers best below the normal float range (root <
+// 1.1e-19) and the conversion of a finite best above FLT_MAX gives +inf.  The
+// diagonals add the rounding of x +- y; uabs = max |u| over the target.
+// Conservative: never skips a possible winner — a wider window only costs time.
 __device__ __forceinline__ double prune_width(int dir, double best, double uq, double uabs) {
-    if (dir < 2) return sqrt(best) * 1.0000000000000004;
-    return sqrt(best * 2.000000000000002) * 1.0000000000000004 + 4.5e-16 * (fabs(uq) + uabs);
+    if (dir < 2) return (double)(__builtin_amdgcn_sqrtf((float)best) * 1.000001f + 1e-18f);
+    return (double)(__builtin_amdgcn_sqrtf((float)(best * 2.000000000000002)) * 1.000001f + 1e-18f) + 4.5e-16 * (fabs(uq) + uabs);
 }
 
 // The same search, also returning the squared distance of the SECOND nearest
@@ -125,8 +130,15 @@ struct Top2 {
     double s1, s2, s3;
 };
 
+// `seed` >= 0 is a position whose distance seeds the top-two list (the previous
+// match).  CENTRED = true starts the walk at the query's own projection (binary
+// search) and skips the seed when the walk meets it: right after a large step the
+// previous match lies many positions away from the query's place, and walking
+// there from the seed would cost as much as an unseeded search.  CENTRED = false
+// walks outwards from the seed itself (no binary search: cheapest when the row
+// has barely moved).  Any seed and either start give the same answer.
 __device__ __forceinline__ Top2 sweep_top2(const double2* sxy, const int32_t* sorig, int m, int dir, double uabs,
-                                           double qx, double qy, int start) {
+                                           double qx, double qy, int seed, bool CENTRED) {
     const double uq = proj(dir, qx, qy);
     Top2 t;
     t.p1 = 0; t.p2 = -1;
@@ -134,18 +146,21 @@ __device__ __forceinline__ Top2 sweep_top2(const double2* sxy, const int32_t* so
     int r1 = 0x7fffffff, r2 = 0x7fffffff;
     double thr = __builtin_inf();
     int lo, hi;
-    if (start >= 0 && start < m) {
-        const double2 c = sxy[start];
+    const bool seeded = seed >= 0 && seed < m;
+    if (seeded) {
+        const double2 c = sxy[seed];
         const double dx = qx - c.x, dy = qy - c.y;
         double s = 0.0;
         s += dx * dx;
         s += dy * dy;
-        t.s1 = s; t.p1 = start; r1 = sorig[start];
-        lo = start - 1; hi = start + 1;
-    } else {
+        t.s1 = s; t.p1 = seed; r1 = sorig[seed];
+    }
+    if (seeded && !CENTRED) { lo = seed - 1; hi = seed + 1; }
+    else {
         hi = sweep_lower_bound(sxy, m, dir, uq);
         lo = hi - 1;
     }
+    const int skip = seeded && CENTRED ? seed : -1;
     while (lo >= 0 || hi < m) {
 #pragma unroll
         for (int side = 0; side < 2; ++side) {
@@ -156,7 +171,7 @@ __device__ __forceinline__ Top2 sweep_top2(const double2* sxy, const int32_t* so
                 const double du = right ? proj(dir, c.x, c.y) - uq : uq - proj(dir, c.x, c.y);
                 if (du > thr) { if (right) hi = m; else lo = -1; }      // everything further out is farther than the third
                 else {
-                    if (true) {   // a candidate before the window costs five flops; testing for it costs a mask branch
+                    if (i != skip) {
                         const double dx = qx - c.x, dy = qy - c.y;
                         double s = 0.0;
                         s += dx * dx;
@@ -184,25 +199,29 @@ __device__ __forceinline__ Top2 sweep_top2(const double2* sxy, const int32_t* so
 }
 
 // 1-NN of (qx, qy) in the sorted cloud.  Returns the sorted position; d2 is the
-// squared distance; ties go to the lowest original row (sorig).  `start` >= 0 is
-// a position to start from (the previous iteration's match: it seeds the bound
-// and replaces the binary search); any value gives the same answer.
+// squared distance; ties go to the lowest original row (sorig).  `seed` >= 0 is a
+// position whose distance seeds the bound (the previous iteration's match); the
+// walk starts at the query's own projection (CENTRED: binary search; meeting the
+// seed again is harmless, it ties with itself) or at the seed.  Same answer for
+// any seed and either start.
 __device__ __forceinline__ int sweep_nn(const double2* sxy, const int32_t* sorig, int m, int dir, double uabs,
-                                        double qx, double qy, int start, double& d2_out) {
+                                        double qx, double qy, int seed, bool CENTRED, double& d2_out) {
     const double uq = proj(dir, qx, qy);
     double best = __builtin_inf(), thr = __builtin_inf();
     int bpos = 0, brow = 0x7fffffff;
     int lo, hi;
-    if (start >= 0 && start < m) {
-        const double2 c = sxy[start];
+    const bool seeded = seed >= 0 && seed < m;
+    if (seeded) {
+        const double2 c = sxy[seed];
         const double dx = qx - c.x, dy = qy - c.y;
         double s = 0.0;
         s += dx * dx;
         s += dy * dy;
-        best = s; bpos = start; brow = sorig[start];
+        best = s; bpos = seed; brow = sorig[seed];
         thr = prune_width(dir, best, uq, uabs);
-        lo = start - 1; hi = start + 1;
-    } else {
+    }
+    if (seeded && !CENTRED) { lo = seed - 1; hi = seed + 1; }
+    else {
         hi = sweep_lower_bound(sxy, m, dir, uq);
         lo = hi - 1;
     }
@@ -212,17 +231,15 @@ __device__ __forceinline__ int sweep_nn(const double2* sxy, const int32_t* sorig
             const double du = proj(dir, c.x, c.y) - uq;
             if (du > thr) hi = m;                               // everything further right is farther still
             else {
-                if (true) {   // a candidate before the window costs five flops; testing for it costs a mask branch
-                    const double dx = qx - c.x, dy = qy - c.y;
-                    double s = 0.0;
-                    s += dx * dx;
-                    s += dy * dy;
-                    if (s <= best) {
-                        const int row = sorig[hi];
-                        if (s < best || row < brow) {
-                            if (s < best) thr = prune_width(dir, s, uq, uabs);
-                            best = s; bpos = hi; brow = row;
-                        }
+                const double dx = qx - c.x, dy = qy - c.y;
+                double s = 0.0;
+                s += dx * dx;
+                s += dy * dy;
+                if (s <= best) {
+                    const int row = sorig[hi];
+                    if (s < best || row < brow) {
+                        if (s < best) thr = prune_width(dir, s, uq, uabs);
+                        best = s; bpos = hi; brow = row;
                     }
                 }
                 ++hi;
@@ -233,17 +250,15 @@ __device__ __forceinline__ int sweep_nn(const double2* sxy, const int32_t* sorig
             const double du = uq - proj(dir, c.x, c.y);
             if (du > thr) lo = -1;
             else {
-                if (true) {   // a candidate before the window costs five flops; testing for it costs a mask branch
-                    const double dx = qx - c.x, dy = qy - c.y;
-                    double s = 0.0;
-                    s += dx * dx;
-                    s += dy * dy;
-                    if (s <= best) {
-                        const int row = sorig[lo];
-                        if (s < best || row < brow) {
-                            if (s < best) thr = prune_width(dir, s, uq, uabs);
-                            best = s; bpos = lo; brow = row;
-                        }
+                const double dx = qx - c.x, dy = qy - c.y;
+                double s = 0.0;
+                s += dx * dx;
+                s += dy * dy;
+                if (s <= best) {
+                    const int row = sorig[lo];
+                    if (s < best || row < brow) {
+                        if (s < best) thr = prune_width(dir, s, uq, uabs);
+                        best = s; bpos = lo; brow = row;
                     }
                 }
                 --lo;

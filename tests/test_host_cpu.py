@@ -201,3 +201,56 @@ def test_sharded_replay_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "REPLAY_OK 2" in r.stdout
+
+
+def test_bench_self_launch_decision():
+    """`python bench.py --gpus 2` without WORLD_SIZE (how the driver starts it) must decide to spawn child ranks
+    under torch.distributed.run BEFORE torch is imported in the parent (never re-exec a process that touched the GPU)."""
+    import json
+    code = ("import sys, runpy\n"
+            f"sys.argv = [{os.path.join(REPO, 'bench.py')!r}, '--gpus', '2', '--steps', '3', '--warmup', '1']\n"
+            "try:\n"
+            f"    runpy.run_path({os.path.join(REPO, 'bench.py')!r}, run_name='__main__')\n"
+            "except SystemExit as e:\n"
+            "    assert e.code == 0, e.code\n"
+            "assert 'torch' not in sys.modules, 'the launching parent imported torch'\n"
+            "print('PARENT_CLEAN')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["ICPMI_BENCH_DRYLAUNCH"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "PARENT_CLEAN" in r.stdout
+    cmd = json.loads(r.stdout.splitlines()[0])["launch"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
+    i = cmd.index(os.path.join(REPO, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    # under a launcher (WORLD_SIZE set) the same command line does not spawn again: it goes on to need a GPU
+    env2 = dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                        env=env2, timeout=300)
+    assert "launch" not in r2.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert r2.returncode != 0 and "no CPU fallback" in (r2.stdout + r2.stderr)
+
+
+def test_bench_refuses_stale_pmc_traffic(tmp_path, monkeypatch):
+    """roofline.traffic comes from a committed rocprofv3 --pmc summary; one collected on other kernel sources is refused."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sig = bench.csrc_signature()
+    assert re.fullmatch(r"[0-9a-f]{16}", sig)
+    doc = {"csrc_sha256": sig, "kernels": {"void icpmi::icp2_x<512> [64 workgroups]": {"hbm_bytes_per_launch": 123}}}
+    f = tmp_path / "pmc.json"
+    f.write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "PMC_TRAFFIC", str(f))
+    assert bench.pmc_traffic("icp2_", 64)[0] == 123
+    assert bench.pmc_traffic("icp2_", 65)[0] is None
+    doc["csrc_sha256"] = "0" * 16
+    f.write_text(json.dumps(doc))
+    t, why = bench.pmc_traffic("icp2_", 64)
+    assert t is None and "stale" in why

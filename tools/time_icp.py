@@ -9,10 +9,12 @@ if os.environ.get("ICPMI_LIB"):
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["ICPMI_LIB"])
 from icpmi import synth
 from icpmi.batch import IcpBatch
-kw = dict(error_threshold=1e-10, max_iterations=int(os.environ.get("MAXIT", "150")), voxel_size=0.04, method="point_to_line", normal_k=12)
+# MAXIT="0,1,2,3,150": one line per iteration limit — the differences are the marginal cost of each iteration
+maxits = [int(m) for m in os.environ.get("MAXIT", "150").split(",")]
 Bs = [int(a) for a in sys.argv[1:]] or [64]
 srcs, tgts = synth.loop_closure_batch(max(Bs), seed0=1000)
-for B in Bs:
+for B, maxit in [(B, m) for B in Bs for m in maxits]:
+    kw = dict(error_threshold=1e-10, max_iterations=maxit, voxel_size=0.04, method="point_to_line", normal_k=12)
     b = IcpBatch(srcs[:B] + tgts[:B], np.arange(B), np.arange(B, 2 * B), **kw)
     for _ in range(2):
         b.run()
@@ -21,4 +23,4 @@ for B in Bs:
         b.run(events=e)
     torch.cuda.synchronize()
     it = b.results.cpu().numpy()[:B, 14]
-    print(f"B={B}: icp kernel {np.mean([x.elapsed_time(y) for x, y in ev]):.3f} ms; iterations sum={int(it.sum())} max={int(it.max())} n150={(it == 150).sum()}")
+    print(f"B={B} maxit={maxit}: icp kernel {np.mean([x.elapsed_time(y) for x, y in ev]):.3f} ms; iterations sum={int(it.sum())} max={int(it.max())} n150={(it == 150).sum()}")
