@@ -550,6 +550,20 @@ def bench_raycast(torch, synth, n_scans, with_cpu):
            "roofline": {"bound": "hbm", "achieved": round((8.0 * cells + 16.0 * 2048 * n_scans) / wall / 1e9, 3),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round((8.0 * cells + 16.0 * 2048 * n_scans) / wall / 1e9 / HBM_PEAK_GBS, 6)}}
+    # BASELINE config 4 as written: ONE live update_scan of 2 048 beams (slam.py:552-557) — count + finalise launch
+    g.reset()
+    one_org, one_hits = d_org[:1].contiguous(), torch.from_numpy(hits[0]).cuda()
+    one_off = np.array([0, len(hits[0])], dtype=np.int32)
+    ox, oy = np.floor((org[0, 0] - g.min_x) / 0.05), np.floor((org[0, 1] - g.min_y) / 0.05)
+    hx, hy = np.floor((hits[0][:, 0] - g.min_x) / 0.05), np.floor((hits[0][:, 1] - g.min_y) / 0.05)
+    one_cells = int(np.maximum(np.abs(hx - ox), np.abs(hy - oy)).sum()) + len(hits[0])
+    one_s = timed(torch, lambda: g._apply(one_org, one_hits, one_off))
+    one_bytes = 8.0 * one_cells + 16.0 * len(hits[0])
+    out["single_scan"] = {"workload": "config 4: one update_scan, 2048 beams, data resident in HBM", "us_per_scan": round(one_s * 1e6, 2),
+                          "cell_updates": one_cells, "cells_per_sec": round(one_cells / one_s, 1),
+                          "roofline": {"bound": "hbm", "achieved": round(one_bytes / one_s / 1e9, 3), "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": round(one_bytes / one_s / 1e9 / HBM_PEAK_GBS, 6),
+                                       "note": "two dependent launches (count, finalise): launch-latency bound, ~2 MB of traffic"}}
     if with_cpu:
         import oracle
         ref = np.zeros((g.ny, g.nx), dtype=np.float32)

@@ -59,33 +59,67 @@ struct Icp2Args {
     int max_iterations;
     int method;
     int has_init;
-    int n_lo;                 // this launch registers the pairs whose source has more than n_lo rows (-1: all) ...
-    int skip_over;            // ... and, if set, leaves pairs beyond its THREADS x SMAX rows to a second launch
+    int n_lo, m_lo;           // second launch: only the pairs whose source has more than n_lo rows or whose target more than m_lo
+    int skip_over;            // first launch: leave pairs beyond THREADS x SMAX source rows or lds_points target rows to the second
 };
 
-// Two-level workgroup sum that keeps the many waves cheap: every wave only sums
-// inside its 16-lane rows (4 DPP steps per value) and stores one partial per row,
-// scratch[i*64 + 4*wave + row]; the lead wave then adds the 64 partials of each
-// value (slots of absent waves stay zero).  Fixed trees: reproducible.
+// ── workgroup sums of NV values per thread ───────────────────────────────────────────────────────────
+// Per wave, a TRANSPOSING reduction: v_permlane32_swap exchanges the upper half of one register with the lower
+// half of another, so one add halves the partials of TWO values at once ((a_lo, b_lo) + (a_hi, b_hi)); the
+// 16-lane form (v_permlane16_swap: odd rows of one register against even rows of the other) does the same for
+// the two resulting registers, which leaves four different values in the four 16-lane rows of one register, and
+// the four DPP steps inside the rows then finish all four together: 5 instructions per value instead of the 12
+// of a DPP tree per value, and ONE total per value and wave (not one per row).  The lead wave adds the totals of
+// the waves in wave order.  Every tree is fixed: bitwise reproducible run to run.
+__device__ __forceinline__ double swap_add(double a, double b, bool rows16) {
+    const long long ab = __double_as_longlong(a), bb = __double_as_longlong(b);
+    const unsigned alo = (unsigned)ab, ahi = (unsigned)(ab >> 32), blo = (unsigned)bb, bhi = (unsigned)(bb >> 32);
+    unsigned xl, xh, yl, yh;
+    if (rows16) {
+        const auto r0 = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        xl = r0[0]; yl = r0[1]; xh = r1[0]; yh = r1[1];
+    } else {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        xl = r0[0]; yl = r0[1]; xh = r1[0]; yh = r1[1];
+    }
+    return __longlong_as_double(((long long)xh << 32) | xl) + __longlong_as_double(((long long)yh << 32) | yl);
+}
+
+constexpr int RED_MAXW = 16;                                   // waves per workgroup at most
 template <int NV>
-__device__ __forceinline__ void store_partials(double* scratch, const double (&v)[NV]) {
+constexpr int red_doubles() { return (NV + 3) / 4 * 4 * RED_MAXW; }
+
+// totals of this wave's NV values -> scratch[value * RED_MAXW + wave]
+template <int NV>
+__device__ __forceinline__ void wave_totals(double* scratch, const double (&v)[NV]) {
+    constexpr int NP = (NV + 3) / 4 * 4;
     const int w = wave_id(), l = lane_id();
+    double h[NP / 2];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const double s = row_sum(v[i]);
-        if ((l & 15) == 0) scratch[i * 64 + 4 * w + (l >> 4)] = s;
+    for (int j = 0; j < NP / 2; ++j)                           // lanes 0-31: value 2j, lanes 32-63: value 2j + 1
+        h[j] = swap_add(2 * j < NV ? v[2 * j] : 0.0, 2 * j + 1 < NV ? v[2 * j + 1] : 0.0, false);
+#pragma unroll
+    for (int k = 0; k < NP / 4; ++k) {
+        // rows 0..3 of q: values 4k, 4k + 2, 4k + 1, 4k + 3 (16 partials each)
+        const double q = row_sum(swap_add(h[2 * k], h[2 * k + 1], true));
+        const int row = l >> 4;
+        const int idx = 4 * k + ((row & 1) << 1) + (row >> 1);
+        if ((l & 15) == 0 && idx < NV) scratch[idx * RED_MAXW + w] = q;
     }
 }
 
+// lead wave: v[i] = sum over the waves (in wave order) of scratch[i * RED_MAXW + wave], uniform in every lane
 template <int NV>
-__device__ __forceinline__ void combine_partials(const double* scratch, double (&v)[NV]) {
+__device__ __forceinline__ void combine_totals(const double* scratch, int n_waves, double (&v)[NV]) {
     const int l = lane_id();
+    double s = 0.0;
+    if (l < NV)
+        for (int w = 0; w < n_waves; ++w) s += scratch[l * RED_MAXW + w];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = wave_sum(scratch[i * 64 + l]);
+    for (int i = 0; i < NV; ++i) v[i] = readlane_f64(s, i);
 }
-
-template <int NV>
-constexpr int partial_doubles() { return NV * 64; }
 
 // control block published by wave 0: r (4), t (2), stop flag, mean_p (2), mean_q (2)
 constexpr int CTRL_R = 0, CTRL_T = 4, CTRL_STOP = 6, CTRL_MP = 8, CTRL_MQ = 10, CTRL_DOUBLES = 12;
@@ -98,15 +132,15 @@ constexpr int CTRL_R = 0, CTRL_T = 4, CTRL_STOP = 6, CTRL_MP = 8, CTRL_MQ = 10, 
 #endif
 // THREADS x ICP2_SMAX = most source rows a pair may have on this instantiation
 // TGT_LDS: the prepared target is staged in LDS (<= 4096 points); otherwise it is read in place, through L2
-template <int THREADS, int ICP2_SMAX, bool TGT_LDS>
-__global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_kernel(Icp2Args a) {   // waves/SIMD: 2 x 512, 2 x 768 or 1 x 1024 per CU
+// FILT (with TGT_LDS): the LDS copy carries a float32 image per point instead of the row map (48 B instead of
+// 36 B per point) and the searches judge every candidate on it first (sweep.hpp, "single-precision filter")
+template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT>
+__global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   // 4 waves/SIMD: 2 x 512 or 1 x 1024 per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    __shared__ double redA[partial_doubles<11>()];     // normal equations (10) / centroid sums (5) + carried squared error
-    __shared__ double redB[partial_doubles<4>()];      // cross-covariance
+    __shared__ double redA[red_doubles<11>()];         // normal equations (10) / centroid sums (5) + carried squared error
+    __shared__ double redB[red_doubles<4>()];          // cross-covariance
     __shared__ double ctrl[CTRL_DOUBLES];
-    __shared__ double totals[12];
-    block_sum_init(redA, partial_doubles<11>());
-    block_sum_init(redB, partial_doubles<4>());
+    constexpr int NWAVES = THREADS / ICPMI_WAVE;
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -120,15 +154,19 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
     // The voxel filter leaves the row counts on the device, so the launcher sizes the rows per thread for the usual
     // case and sends the (rare) larger clouds to a second launch of a wider shape: each pair is registered by
     // exactly one of the two (uniform per workgroup, before any barrier).
-    if (N <= a.n_lo || (a.skip_over && N > THREADS * ICP2_SMAX)) return;
+    if (a.skip_over ? (N > THREADS * ICP2_SMAX || (TGT_LDS && M > a.lds_points)) : (a.n_lo >= 0 && N <= a.n_lo && M <= a.m_lo)) return;
 
     // two instantiations, each sees ONE address space behind these pointers
     double2* lds_xy = reinterpret_cast<double2*>(dyn);
     double2* lds_nrm = reinterpret_cast<double2*>(dyn + (size_t)a.lds_points * 16);
-    int32_t* lds_orig = reinterpret_cast<int32_t*>(dyn + (size_t)a.lds_points * 32);
+    int32_t* lds_orig = reinterpret_cast<int32_t*>(dyn + (size_t)a.lds_points * 32);      // !FILT: row map (4 B per point)
+    float4* lds_sq = reinterpret_cast<float4*>(dyn + (size_t)a.lds_points * 32) + 1;     //  FILT: float32 images (16 B per point), one padding entry at either end
     const double2* sxy = TGT_LDS ? lds_xy : a.g_sxy + a.off[tc];
     const double2* snrm = TGT_LDS ? lds_nrm : a.g_snrm + a.off[tc];
     const int32_t* sorig = TGT_LDS ? lds_orig : a.g_sorig + a.off[tc];
+    static_assert(TGT_LDS || !FILT, "the filter images live in LDS");
+    __shared__ int rt_bits;                                      // max(|x - ox|, |y - oy|) over the target, float32 bits
+    if (FILT && tid == 0) rt_bits = 0;
 
     double rt[4] = {1.0, 0.0, 0.0, 1.0}, tt[2] = {0.0, 0.0};
     if (a.has_init) {                                       // icp.py:153-156
@@ -148,12 +186,31 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
         const double2* gx = a.g_sxy + a.off[tc];
         const double2* gn = a.g_snrm + a.off[tc];
         const int32_t* go = a.g_sorig + a.off[tc];
-        if constexpr (TGT_LDS)
+        SweepF filt{0.0, 0.0, 0.0, 0.0f, 0.0f};
+        if constexpr (TGT_LDS && !FILT)
             for (int i = tid; i < M; i += THREADS) {
                 lds_xy[i] = gx[i];
                 lds_orig[i] = go[i];
                 if (use_p2l) lds_nrm[i] = gn[i];
             }
+        if constexpr (FILT) {
+            // float32 images relative to the point in the middle of the sort order (small magnitudes)
+            const double2 o = gx[M >> 1];
+            filt.ox = o.x; filt.oy = o.y; filt.uo = proj(dir, o.x, o.y);
+            float rmax = 0.0f;
+            for (int i = tid; i < M; i += THREADS) {
+                const double2 p = gx[i];
+                lds_xy[i] = p;
+                if (use_p2l) lds_nrm[i] = gn[i];
+                const float4 q = make_float4((float)(p.x - filt.ox), (float)(p.y - filt.oy),
+                                             (float)(proj(dir, p.x, p.y) - filt.uo), __int_as_float(go[i]));
+                lds_sq[i] = q;
+                rmax = fmaxf(rmax, fmaxf(fabsf(q.x), fabsf(q.y)));
+            }
+            if (tid == 0) { lds_sq[-1] = make_float4(0.f, 0.f, 0.f, 0.f); lds_sq[M] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            __syncthreads();                                     // rt_bits = 0 is visible
+            atomicMax(&rt_bits, __float_as_int(rmax));           // non-negative floats order like their bits
+        }
         // moving source rows in registers: row n = s*THREADS + tid
         double px[ICP2_SMAX], py[ICP2_SMAX];
         int pos[ICP2_SMAX];
@@ -196,6 +253,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
         // largest |projection| of the target (the copy is sorted along it): rounding slack of the diagonal axes
         const double2 c_lo = sxy[0], c_hi = sxy[M - 1];
         const double uabs = fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y)));
+        if constexpr (FILT) {
+            filt.rt = __int_as_float(rt_bits) * 1.000001f;
+            filt.ut = fmaxf(fabsf(lds_sq[0].z), fabsf(lds_sq[M - 1].z)) * 1.000001f;     // the images are sorted like the keys
+        }
 
         double e_part = 0.0;          // this thread's share of the squared error of the step just applied
         bool stopped = false;
@@ -205,33 +266,54 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
         for (int it = 0; it < a.max_iterations; ++it) {
             DIAG_T(c0);
             // ── correspondences: exact sweep search in LDS, icp.py:179 ───────
+            // A row whose net displacement since its last search is inside its budget keeps one of its two
+            // candidates (two distances); the others search.
+            bool srch[ICP2_SMAX];
 #pragma unroll
-            for (int s = 0; s < ICP2_SMAX; ++s)
-                if (s < S && s * THREADS + tid < N) {
-                    // |dx| + |dy| >= the distance between the row and its anchor
-                    if ((fabs(px[s] - (double)ax[s]) + fabs(py[s] - (double)ay[s])) * 1.000000001 < (double)budget[s]) {   // match is one of the two kept
-                        // straight-line: a missing second candidate stands in as the first (never better), and only an
-                        // exact tie of the two distances takes a branch (to compare the rows)
-                        const int pa = pos[s], pb = pos2[s] >= 0 ? pos2[s] : pos[s];
-                        const double2 c = sxy[pa], e = sxy[pb];
-                        const double dx = px[s] - c.x, dy = py[s] - c.y;
-                        const double ex = px[s] - e.x, ey = py[s] - e.y;
-                        double q2 = 0.0, w2 = 0.0;
-                        q2 += dx * dx;
-                        q2 += dy * dy;
-                        w2 += ex * ex;
-                        w2 += ey * ey;
-                        bool second_wins = w2 < q2;
-                        if (w2 == q2 && pb != pa) second_wins = sorig[pb] < sorig[pa];
-                        pos[s] = second_wins ? pb : pa;
-                        pos2[s] = pos2[s] >= 0 ? (second_wins ? pa : pb) : -1;
-                    } else if (it < ICP2_PLAIN_ITERS) {
-                        // the first steps move every row by more than any budget: plain 1-NN (smallest window), started at
-                        // the row's own projection — the previous match only seeds the bound (it lies a whole step away)
+            for (int s = 0; s < ICP2_SMAX; ++s) {
+                const bool valid = s < S && s * THREADS + tid < N;
+                // |dx| + |dy| >= the distance between the row and its anchor
+                const bool within = valid && (fabs(px[s] - (double)ax[s]) + fabs(py[s] - (double)ay[s])) * 1.000000001 < (double)budget[s];
+                srch[s] = valid && !within;
+                if (within) {
+                    // straight-line: a missing second candidate stands in as the first (never better), and only an
+                    // exact tie of the two distances takes a branch (to compare the rows)
+                    const int pa = pos[s], pb = pos2[s] >= 0 ? pos2[s] : pos[s];
+                    const double2 c = sxy[pa], e = sxy[pb];
+                    const double dx = px[s] - c.x, dy = py[s] - c.y;
+                    const double ex = px[s] - e.x, ey = py[s] - e.y;
+                    double q2 = 0.0, w2 = 0.0;
+                    q2 += dx * dx;
+                    q2 += dy * dy;
+                    w2 += ex * ex;
+                    w2 += ey * ey;
+                    bool second_wins = w2 < q2;
+                    if (w2 == q2 && pb != pa) {
+                        if constexpr (FILT) second_wins = sweepf_row(lds_sq[pb]) < sweepf_row(lds_sq[pa]);
+                        else second_wins = sorig[pb] < sorig[pa];
+                    }
+                    pos[s] = second_wins ? pb : pa;
+                    pos2[s] = pos2[s] >= 0 ? (second_wins ? pa : pb) : -1;
+                }
+            }
+            if (it < ICP2_PLAIN_ITERS) {
+                // the first steps move every row by more than any budget: plain 1-NN (smallest window), started at
+                // the row's own projection — the previous match only seeds the bound (it lies a whole step away)
+#pragma unroll
+                for (int s = 0; s < ICP2_SMAX; ++s)
+                    if (srch[s]) {
                         double d2s;
-                        pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], true, d2s);
-                    } else {
-                        const Top2 t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], it < ICP2_CENTRED_ITERS);
+                        if constexpr (FILT) pos[s] = sweepf_nn(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], true, d2s);
+                        else pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], true, d2s);
+                    }
+            } else {
+                const bool centred = it < ICP2_CENTRED_ITERS;
+#pragma unroll
+                for (int s = 0; s < ICP2_SMAX; ++s)
+                    if (srch[s]) {
+                        Top2 t2;
+                        if constexpr (FILT) t2 = sweepf_top2(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], centred);
+                        else t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], centred);
                         pos[s] = t2.p1; pos2[s] = t2.p2;
                         const double d1 = sqrt(t2.s1), d3 = sqrt(t2.s3);
                         // minus the rounding of the single-precision anchor; rounded down
@@ -244,7 +326,7 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
                         atomicAdd(&res[8], 1.0);             // diag: number of searches run by this pair
 #endif
                     }
-                }
+            }
 #ifdef ICPMI_DIAG
             __syncthreads();          // diag only: charge the slowest wave's search to the search phase
 #endif
@@ -280,19 +362,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
                     acc[9] += 1.0;
                 }
                 acc[10] = e_part;
-                store_partials<11>(redA, acc);
-                __syncthreads();
-                // the 11 sums of 64 partials are spread over the waves (one value each), so the
-                // serial lead section only reads 11 totals
-                for (int i = wave_id(); i < 11; i += THREADS / ICPMI_WAVE) {
-                    const double tsum = wave_sum(redA[i * 64 + lane_id()]);
-                    if (lane_id() == 0) totals[i] = tsum;
-                }
+                wave_totals<11>(redA, acc);
                 __syncthreads();
                 DIAG_SET(c2);
                 if (lead) {
-#pragma unroll
-                    for (int i = 0; i < 11; ++i) acc[i] = totals[i];
+                    combine_totals<11>(redA, NWAVES, acc);
                     bool stop = false;
                     if (it > 0) {                                                  // finish step it-1: icp.py:215-220
                         err = acc[10] / (double)N;
@@ -345,11 +419,11 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
                     m[0] += px[s]; m[1] += py[s]; m[2] += q.x; m[3] += q.y; m[4] += 1.0;
                 }
                 m[5] = e_part;
-                store_partials<6>(redA, m);
+                wave_totals<6>(redA, m);
                 __syncthreads();
                 DIAG_SET(c2);
                 if (lead) {
-                    combine_partials<6>(redA, m);
+                    combine_totals<6>(redA, NWAVES, m);
                     bool stop = false;
                     if (it > 0) {
                         err = m[5] / (double)N;
@@ -377,10 +451,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
                     const double pcx = px[s] - mpx, pcy = py[s] - mpy, qcx = q.x - mqx, qcy = q.y - mqy;
                     W[0] += pcx * qcx; W[1] += pcx * qcy; W[2] += pcy * qcx; W[3] += pcy * qcy;
                 }
-                store_partials<4>(redB, W);
+                wave_totals<4>(redB, W);
                 __syncthreads();
                 if (lead) {
-                    combine_partials<4>(redB, W);
+                    combine_totals<4>(redB, NWAVES, W);
                     double r[4], t[2];
                     kabsch2(W, r);                                                 // icp.py:202-206
                     double s0 = 0.0, s1 = 0.0;
@@ -428,10 +502,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
             // the last step's error has not been reduced yet: icp.py:215-223 for it = max_iterations - 1
             double e[1] = {e_part};
             __syncthreads();                      // redA may still be read by the lead wave of the last iteration
-            store_partials<1>(redA, e);
+            wave_totals<1>(redA, e);
             __syncthreads();
             if (lead) {
-                combine_partials<1>(redA, e);
+                combine_totals<1>(redA, NWAVES, e);
                 err = e[0] / (double)N;
                 iters = a.max_iterations;
                 delta = fabs(prev - err);
@@ -464,50 +538,62 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     a.g_snrm = (const double2*)(b + (size_t)total_rows * 16);
     a.g_sorig = (const int32_t*)(b + (size_t)total_rows * 32);
     a.g_dir = (const int32_t*)(b + (size_t)total_rows * 36);
-    int cap = 64;
-    while (cap < max_tgt_n) cap <<= 1;
-    a.lds_points = cap;
     a.error_threshold = p->error_threshold; a.max_corr_dist = p->max_corr_dist;
     a.max_iterations = p->max_iterations; a.method = p->method; a.has_init = p->has_init;
     const bool in_lds = max_tgt_n <= 4096;
-    const size_t lds = in_lds ? (size_t)cap * 36 : 0;
     // Workgroup shape by source size (rows per thread bounded by the instantiation).  ICPMI_ICP2_SHAPE = "TxS"
-    // (threads x rows per thread, one of the instantiations below) overrides the choice for experiments.
+    // (threads x rows per thread, one of the instantiations below) overrides the choice for experiments;
+    // ICPMI_ICP2_FILTER=0 turns the single-precision filter off.
     int T = 0, SM = 0;
     if (const char* env = getenv("ICPMI_ICP2_SHAPE")) {
         if (sscanf(env, "%dx%d", &T, &SM) != 2) { T = 0; SM = 0; }
     }
+    const char* fenv = getenv("ICPMI_ICP2_FILTER");
+    const bool want_filter = !(fenv && fenv[0] == '0');
 #define ICPMI_ICP2_GO(TT, SS)                                                                                                    \
-    do { if (in_lds) ICPMI_ICP2_GO2(TT, SS, true); else ICPMI_ICP2_GO2(TT, SS, false); } while (0)
-#define ICPMI_ICP2_GO2(TT, SS, L)                                                                                                \
     do {                                                                                                                         \
-        if (hipFuncSetAttribute((const void*)icp2_fused_kernel<TT, SS, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != \
-            hipSuccess) return ICPMI_ERR_HIP;                                                                                    \
-        icp2_fused_kernel<TT, SS, L><<<n_pairs, TT, lds, st>>>(a);                                                                 \
+        if (!in_lds) ICPMI_ICP2_GO2(TT, SS, false, false);                                                                      \
+        else if (filter) ICPMI_ICP2_GO2(TT, SS, true, true);                                                                    \
+        else ICPMI_ICP2_GO2(TT, SS, true, false);                                                                               \
     } while (0)
-    a.n_lo = -1; a.skip_over = 0;
+#define ICPMI_ICP2_GO2(TT, SS, L, F)                                                                                             \
+    do {                                                                                                                         \
+        if (hipFuncSetAttribute((const void*)icp2_fused_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                                   \
+        icp2_fused_kernel<TT, SS, L, F><<<n_pairs, TT, lds, st>>>(a);                                                             \
+    } while (0)
+    a.n_lo = -1; a.m_lo = 0; a.skip_over = 0;
     int T2 = 0, SM2 = 0;                // second launch for the pairs the first shape cannot hold
+    const bool many = n_pairs >= 1024;
     if (T == 0) {
         // A voxel-filtered 2 048-beam scan keeps ~1 400 rows: 512 threads x 3 rows, two workgroups per CU — one pair's
-        // serial solve and barrier waits overlap the other's search.  Sources that keep more than 1 536 rows go to a
+        // serial solve and barrier waits overlap the other's search.  Clouds that keep more than 1 536 rows go to a
         // second launch (1 024 threads).  With few pairs (less than two per CU) 1 024 threads x 2 rows finish a pair
         // soonest.
-        const bool many = n_pairs >= 1024;
         if (max_src_n <= 1024) { T = 512; SM = 2; }
         else if (many) { T = 512; SM = 3; }
         else if (max_src_n <= 2048) { T = 1024; SM = 2; }
         else { T = 1024; SM = 4; }
     }
-    if (T * SM < max_src_n) { T2 = 1024; SM2 = max_src_n <= 2048 ? 2 : 4; a.skip_over = 1; }
+    // LDS copy of the target: 36 B per point, 48 B with the float32 images of the filter.  Two workgroups of the
+    // 512-thread shapes share a CU only up to 1 536 filter points (2 x 73.7 KB): larger targets, like larger
+    // sources, are left to the second launch.  The filter needs <= 2 048 points (96 KB, one workgroup per CU).
+    int cap1 = (T == 512 && many && in_lds && want_filter && max_tgt_n > 1536) ? 1536 : max_tgt_n;
+    if (T * SM < max_src_n || cap1 < max_tgt_n) { T2 = 1024; SM2 = max_src_n <= 2048 ? 2 : 4; a.skip_over = 1; }
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
             if (!T2) break;
-            a.n_lo = T * SM; a.skip_over = 0; T = T2; SM = SM2;
+            a.n_lo = T * SM; a.m_lo = cap1; a.skip_over = 0; T = T2; SM = SM2; cap1 = max_tgt_n;
         }
+        int cap = 64;
+        while (cap < cap1) cap <<= 1;
+        if (cap1 > 1024 && cap1 <= 1536) cap = 1536;
+        a.lds_points = cap;
+        const bool filter = in_lds && want_filter && cap <= 2048;
+        const size_t lds = in_lds ? (filter ? (size_t)cap * 48 + 32 : (size_t)cap * 36) : 0;
         if (T == 512 && SM == 2) ICPMI_ICP2_GO(512, 2);
         else if (T == 512 && SM == 3) ICPMI_ICP2_GO(512, 3);
         else if (T == 512 && SM == 4) ICPMI_ICP2_GO(512, 4);
-        else if (T == 768 && SM == 2) ICPMI_ICP2_GO(768, 2);
         else if (T == 1024 && SM == 2) ICPMI_ICP2_GO(1024, 2);
         else if (T == 1024 && SM == 4) ICPMI_ICP2_GO(1024, 4);
         else return ICPMI_ERR_ARG;

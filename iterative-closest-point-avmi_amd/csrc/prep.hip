@@ -9,13 +9,16 @@
 
 namespace icpmi {
 
+#ifndef ICPMI_PREP_WPS
+#define ICPMI_PREP_WPS 6      // waves per SIMD the k-NN kernel is compiled for up to KK = 13: three workgroups per CU
+#endif
 constexpr int PREP_THREADS = 512;
 constexpr int PREP_MAXW = PREP_THREADS / ICPMI_WAVE;
 constexpr int PREP_MAX_POINTS = 4096;   // sorted copy (20 B/pt) + sort scratch (12 B/pt) stay in LDS
 
 // KK = capacity of the per-query neighbour list (0: no normals); GRID: k-NN through a grid instead of the sweep
 template <int KK, bool GRID>
-__global__ __launch_bounds__(PREP_THREADS, (KK <= 16 ? 4 : 2)) void prep_targets_kernel(   // at least two workgroups per CU up to KK = 16
+__global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 16 ? 4 : 2))) void prep_targets_kernel(   // three workgroups per CU up to KK = 13, two up to 16
     const double* __restrict__ pts, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
     const int32_t* __restrict__ cloud_ids, int k, double2* __restrict__ g_sxy, double2* __restrict__ g_snrm,
     int32_t* __restrict__ g_sorig, int32_t* __restrict__ g_dir, double* __restrict__ out_normals, int lds_points,

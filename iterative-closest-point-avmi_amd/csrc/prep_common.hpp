@@ -64,6 +64,28 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
     return dir;
 }
 
+// Batcher's odd-even merge sort as a list of compare-exchange pairs (a < b), for N inputs: the network for the next
+// power of two with every pair that touches an index >= N dropped (those inputs would be +inf and never move).
+template <int N>
+struct SortNet {
+    int n;
+    int a[N * 8], b[N * 8];
+};
+template <int N>
+constexpr SortNet<N> make_sortnet() {
+    SortNet<N> r{};
+    int P = 1;
+    while (P < N) P <<= 1;
+    for (int p = 1; p < P; p <<= 1)
+        for (int k = p; k >= 1; k >>= 1)
+            for (int j = k % p; j <= P - 1 - k; j += 2 * k)
+                for (int i = 0; i <= (k - 1 < P - j - k - 1 ? k - 1 : P - j - k - 1); ++i)
+                    if ((i + j) / (p * 2) == (i + j + k) / (p * 2) && i + j + k < N) {
+                        r.a[r.n] = i + j; r.b[r.n] = i + j + k; ++r.n;
+                    }
+    return r;
+}
+
 // k best (d2, sorted position), ascending by (d2, original row).  Every index is a compile-time constant
 // (template recursion), so the lists stay in registers.  The rows are not kept: they only order candidates
 // at exactly equal distances, where they are read from `sorig` (LDS / L2) on the spot.
@@ -76,6 +98,39 @@ struct TopKP {
         if constexpr (I < KK) { d[I] = __builtin_inf(); p[I] = 0; init_from<I + 1>(); }
     }
     __device__ __forceinline__ void init() { init_from<0>(); }
+    // The list filled with the KK consecutive sorted positions b0 .. b0+KK-1 and put in order by a fixed sorting
+    // network: every lane does the same KK distances and the same compare-exchanges (selects, no branch but on an
+    // exact tie of distances), instead of KK insertions that each lane would bubble to a different depth.
+    template <int I>
+    __device__ __forceinline__ void load_from(const double2* sxy, int b0, const double2 q) {
+        if constexpr (I < KK) {
+            const double2 c = sxy[b0 + I];
+            const double dx = q.x - c.x, dy = q.y - c.y;
+            double s = 0.0;
+            s += dx * dx;
+            s += dy * dy;
+            d[I] = s; p[I] = b0 + I;
+            load_from<I + 1>(sxy, b0, q);
+        }
+    }
+    static constexpr SortNet<KK> NET = make_sortnet<KK>();
+    template <int C>
+    __device__ __forceinline__ void net_from(const int32_t* sorig) {
+        if constexpr (C < NET.n) {
+            constexpr int A = NET.a[C], B = NET.b[C];
+            bool sw = d[B] < d[A];
+            if (d[B] == d[A]) sw = sorig[p[B]] < sorig[p[A]];        // exact tie: original rows decide
+            const double da = d[A], db = d[B];
+            const int pa = p[A], pb = p[B];
+            d[A] = sw ? db : da; d[B] = sw ? da : db;
+            p[A] = sw ? pb : pa; p[B] = sw ? pa : pb;
+            net_from<C + 1>(sorig);
+        }
+    }
+    __device__ __forceinline__ void init_block(const double2* sxy, const int32_t* sorig, int b0, const double2 q) {
+        load_from<0>(sxy, b0, q);
+        net_from<0>(sorig);
+    }
     template <int I>
     __device__ __forceinline__ void bubble(const int32_t* sorig) {
         if constexpr (I > 0) {
@@ -144,39 +199,45 @@ __device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* 
                                              double2* __restrict__ out_sorted, double* __restrict__ out_rows) {
     const double2 c_lo = sxy[0], c_hi = sxy[M - 1];
     const double uabs = fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y)));
+    const double pa = dir == 1 ? 0.0 : 1.0, pb = dir == 0 ? 0.0 : (dir == 3 ? -1.0 : 1.0);    // u = x*pa + y*pb (proj)
     for (int s = s_begin + threadIdx.x; s < s_end; s += blockDim.x) {
         const double2 q = sxy[s];
-        const double uq = proj(dir, q.x, q.y);
+        const double uq = q.x * pa + q.y * pb;
         TopKP<KK> top;
-        top.init();
-        top.push(0.0, s, sorig);
         // the sweep on one side ends when the gap along the axis alone exceeds the current kk-th best
         // distance (inf until kk neighbours are known), compared in squares: no sqrt on the path
         // (gap_exceeds, sweep.hpp: exact on x / y; the diagonals allow for the rounding of x +- y)
         double bound = __builtin_inf();
         const double eps = dir < 2 ? 0.0 : 4.5e-16 * (fabs(uq) + uabs);
         const double widen = dir < 2 ? 1.0 : 2.000000000000002;
-        int lo = s - 1, hi = s + 1;
+        int lo, hi;
+        if (M >= KK) {
+            // start from the KK points around the query's own sorted position (it is one of them): on a wall that
+            // runs alone through the sweep window these ARE its neighbours and everything after is rejected
+            const int b0 = min(max(s - KK / 2, 0), M - KK);
+            top.init_block(sxy, sorig, b0, q);
+            bound = (kk == KK ? top.d[KK - 1] : top.kth(kk - 1)) * widen;
+            lo = b0 - 1; hi = b0 + KK;
+        } else {
+            top.init();
+            top.push(0.0, s, sorig);
+            lo = s - 1; hi = s + 1;
+        }
+        // one candidate from each open side per round, both loaded before use, the next pair fetched meanwhile
+        double2 cr = sweep_load(sxy, hi, M), cl = sweep_load(sxy, lo, M);
         while (lo >= 0 || hi < M) {
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const bool right = side == 0;
-                if (right ? hi < M : lo >= 0) {
-                    const int i = right ? hi : lo;
-                    const double2 c = sxy[i];
-                    const double du = right ? proj(dir, c.x, c.y) - uq : uq - proj(dir, c.x, c.y);
-                    const double gap = du - eps;
-                    if (gap > 0.0 && gap * gap > bound) { if (right) hi = M; else lo = -1; }
-                    else {
-                        const double dx = q.x - c.x, dy = q.y - c.y;
-                        double d2 = 0.0;
-                        d2 += dx * dx;
-                        d2 += dy * dy;
-                        if (top.push(d2, i, sorig)) bound = (kk == KK ? top.d[KK - 1] : top.kth(kk - 1)) * widen;
-                        if (right) ++hi; else --lo;
-                    }
-                }
-            }
+            const double2 nr = sweep_load(sxy, hi + 1, M), nl = sweep_load(sxy, lo - 1, M);
+            const double gr = (cr.x * pa + cr.y * pb) - uq - eps, gl = uq - (cl.x * pa + cl.y * pb) - eps;
+            const bool inr = hi < M && !(gr > 0.0 && gr * gr > bound);
+            const bool inl = lo >= 0 && !(gl > 0.0 && gl * gl > bound);
+            const double sr = sweep_d2(q.x, q.y, cr), sl = sweep_d2(q.x, q.y, cl);
+            bool changed = false;
+            if (inr) changed = top.push(sr, hi, sorig);
+            if (inl) changed = top.push(sl, lo, sorig) || changed;
+            if (changed) bound = (kk == KK ? top.d[KK - 1] : top.kth(kk - 1)) * widen;
+            hi = inr ? hi + 1 : M;
+            lo = inl ? lo - 1 : -1;
+            cr = nr; cl = nl;
         }
         emit_normal<KK>(top, kk, sxy, sorig, s, out_sorted, out_rows);
     }

@@ -130,6 +130,7 @@ struct Top2 {
     double s1, s2, s3;
 };
 
+#ifdef ICPMI_SWEEP_V1
 // `seed` >= 0 is a position whose distance seeds the top-two list (the previous
 // match).  CENTRED = true starts the walk at the query's own projection (binary
 // search) and skips the seed when the walk meets it: right after a large step the
@@ -268,5 +269,318 @@ __device__ __forceinline__ int sweep_nn(const double2* sxy, const int32_t* sorig
     d2_out = best;
     return bpos;
 }
+
+#else
+// ── batched, predicated walks (the searches of the fused ICP kernel) ─────────────────────────────────
+// One loop round takes ONE candidate from each open side; both are loaded before either is used and the
+// next pair is fetched while the current one is evaluated, so a round waits for LDS once instead of twice
+// and carries no branch per candidate: the window test, the distance and the update are straight-line
+// selects.  Only an exact tie of squared distances (duplicates, lattices) leaves the straight line, to
+// compare original rows.  The bound `thr` is refreshed once per round (a stale bound is only wider).
+// Same answers as the exhaustive scan for any seed and either start.
+struct SweepAxis {
+    double a, b;        // projection u = x*a + y*b, factors from {0, +-1}: exact
+    double uq, slack, two;
+    __device__ __forceinline__ SweepAxis(int dir, double qx, double qy, double uabs) {
+        a = dir == 1 ? 0.0 : 1.0;
+        b = dir == 0 ? 0.0 : (dir == 3 ? -1.0 : 1.0);
+        uq = qx * a + qy * b;
+        slack = dir < 2 ? 0.0 : 4.5e-16 * (fabs(uq) + uabs);          // rounding of x +- y on the diagonals
+        two = dir < 2 ? 1.0 : 2.000000000000002;                      // (dx +- dy)^2 <= 2 (dx^2 + dy^2)
+    }
+    // prune_width() without the branch on the axis (x * 1.0 and + 0.0 are exact)
+    __device__ __forceinline__ double width(double best) const {
+        return (double)(__builtin_amdgcn_sqrtf((float)(best * two)) * 1.000001f + 1e-18f) + slack;
+    }
+    __device__ __forceinline__ double u(const double2 c) const { return c.x * a + c.y * b; }
+};
+
+__device__ __forceinline__ double2 sweep_load(const double2* sxy, int i, int m) { return sxy[min(max(i, 0), m - 1)]; }
+
+__device__ __forceinline__ double sweep_d2(double qx, double qy, const double2 c) {
+    const double dx = qx - c.x, dy = qy - c.y;
+    double s = 0.0;
+    s += dx * dx;
+    s += dy * dy;
+    return s;
+}
+
+// `seed` >= 0 is a position whose distance seeds the top-two list (the previous
+// match).  CENTRED = true starts the walk at the query's own projection (binary
+// search) and skips the seed when the walk meets it: right after a large step the
+// previous match lies many positions away from the query's place, and walking
+// there from the seed would cost as much as an unseeded search.  CENTRED = false
+// walks outwards from the seed itself (no binary search: cheapest when the row
+// has barely moved).  Any seed and either start give the same answer.
+__device__ __forceinline__ Top2 sweep_top2(const double2* sxy, const int32_t* sorig, int m, int dir, double uabs,
+                                           double qx, double qy, int seed, bool CENTRED) {
+    const SweepAxis ax(dir, qx, qy, uabs);
+    Top2 t;
+    t.p1 = 0; t.p2 = -1;
+    t.s1 = t.s2 = t.s3 = __builtin_inf();
+    double thr = __builtin_inf();
+    int lo, hi;
+    const bool seeded = seed >= 0 && seed < m;
+    if (seeded) { t.s1 = sweep_d2(qx, qy, sxy[seed]); t.p1 = seed; }
+    if (seeded && !CENTRED) { lo = seed - 1; hi = seed + 1; }
+    else {
+        hi = sweep_lower_bound(sxy, m, dir, ax.uq);
+        lo = hi - 1;
+    }
+    const int skip = seeded && CENTRED ? seed : -1;
+    double2 cr = sweep_load(sxy, hi, m), cl = sweep_load(sxy, lo, m);
+    while (lo >= 0 || hi < m) {
+        const double2 nr = sweep_load(sxy, hi + 1, m), nl = sweep_load(sxy, lo - 1, m);
+        const bool inr = hi < m && !(ax.u(cr) - ax.uq > thr);          // else: everything further right is farther than the third
+        const bool inl = lo >= 0 && !(ax.uq - ax.u(cl) > thr);
+        const double sr = sweep_d2(qx, qy, cr), sl = sweep_d2(qx, qy, cl);
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int i = side == 0 ? hi : lo;
+            const double s = side == 0 ? sr : sl;
+            const bool take = (side == 0 ? inr : inl) && i != skip;
+            if (take && (s == t.s1 || s == t.s2)) {
+                // exact tie with a kept distance: order by original row (the rule everywhere: (distance, row) ascending)
+                const int row = sorig[i], r1 = sorig[t.p1], r2 = t.p2 >= 0 ? sorig[t.p2] : 0x7fffffff;
+                if (s < t.s1 || (s == t.s1 && row < r1)) { t.s3 = t.s2; t.s2 = t.s1; t.p2 = t.p1; t.s1 = s; t.p1 = i; }
+                else if (s < t.s2 || row < r2) { t.s3 = t.s2; t.s2 = s; t.p2 = i; }
+                else t.s3 = s;                                         // tie with the second, lost on the row
+            } else {
+                const bool c1 = take && s < t.s1, c2 = take && s < t.s2, c3 = take && s < t.s3;
+                t.s3 = c2 ? t.s2 : (c3 ? s : t.s3);
+                t.s2 = c1 ? t.s1 : (c2 ? s : t.s2);
+                t.p2 = c1 ? t.p1 : (c2 ? i : t.p2);
+                t.s1 = c1 ? s : t.s1;
+                t.p1 = c1 ? i : t.p1;
+            }
+        }
+        thr = ax.width(t.s3);
+        hi = inr ? hi + 1 : m;
+        lo = inl ? lo - 1 : -1;
+        cr = nr; cl = nl;
+    }
+    return t;
+}
+
+// 1-NN of (qx, qy) in the sorted cloud.  Returns the sorted position; d2 is the
+// squared distance; ties go to the lowest original row (sorig).  `seed` >= 0 is a
+// position whose distance seeds the bound (the previous iteration's match); the
+// walk starts at the query's own projection (CENTRED: binary search) or at the
+// seed.  Same answer for any seed and either start.
+__device__ __forceinline__ int sweep_nn(const double2* sxy, const int32_t* sorig, int m, int dir, double uabs,
+                                        double qx, double qy, int seed, bool CENTRED, double& d2_out) {
+    const SweepAxis ax(dir, qx, qy, uabs);
+    double best = __builtin_inf(), thr = __builtin_inf();
+    int bpos = 0;
+    int lo, hi;
+    const bool seeded = seed >= 0 && seed < m;
+    if (seeded) {
+        best = sweep_d2(qx, qy, sxy[seed]); bpos = seed;
+        thr = ax.width(best);
+    }
+    if (seeded && !CENTRED) { lo = seed - 1; hi = seed + 1; }
+    else {
+        hi = sweep_lower_bound(sxy, m, dir, ax.uq);
+        lo = hi - 1;
+    }
+    double2 cr = sweep_load(sxy, hi, m), cl = sweep_load(sxy, lo, m);
+    while (lo >= 0 || hi < m) {
+        const double2 nr = sweep_load(sxy, hi + 1, m), nl = sweep_load(sxy, lo - 1, m);
+        const bool inr = hi < m && !(ax.u(cr) - ax.uq > thr);          // else: everything further right is farther still
+        const bool inl = lo >= 0 && !(ax.uq - ax.u(cl) > thr);
+        const double sr = sweep_d2(qx, qy, cr), sl = sweep_d2(qx, qy, cl);
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int i = side == 0 ? hi : lo;
+            const double s = side == 0 ? sr : sl;
+            const bool take = side == 0 ? inr : inl;
+            if (take && s == best && i != bpos) {                      // exact tie: the lowest original row wins
+                if (sorig[i] < sorig[bpos]) bpos = i;
+            }
+            const bool lt = take && s < best;
+            best = lt ? s : best;
+            bpos = lt ? i : bpos;
+        }
+        thr = ax.width(best);
+        hi = inr ? hi + 1 : m;
+        lo = inl ? lo - 1 : -1;
+        cr = nr; cl = nl;
+    }
+    d2_out = best;
+    return bpos;
+}
+
+
+// ── single-precision filter in front of the exact walk ───────────────────────────────────────────────
+// The walks above spend ten float64 instructions on every candidate of the window (projection, gap,
+// distance), and float64 issues at a fraction of the float32 rate.  Nearly all candidates lose.  So the
+// target also carries a float32 image per sorted position — (x - ox, y - oy, u - uo, original row), relative
+// to a point o of the cloud so that the magnitudes stay small — and a candidate is first judged on that
+// image with rigorous margins; only one that MIGHT enter the result is then evaluated in float64 exactly as
+// before.  Results are therefore bit-identical; the filter can only cost a spurious exact evaluation.
+//
+// Margins (E, mu below; 2^-23 = 1.19e-7).  Every float32 coordinate is the rounding of a float64 difference,
+// so it is within 2^-24 relative of the true recentred coordinate, and the float32 difference q - c within
+// e <= 2^-23 (|q'| + |c'|) of the true one (both roundings + the subtraction's).  With d the true distance:
+// |s32 - d^2| <= 2 sqrt(2) e d + 2 e^2 + 2^-22 s32, hence d <= B  =>  s32 <= (B + 1.5 e)^2 (1 + 2^-21): a
+// candidate is skipped only when s32 exceeds that, with B a float32 upper bound of the root of the bound.
+// The window test uses u32 = fl32(fl64(u - uo)), a monotone function of the sort key, so "this candidate's gap
+// exceeds W" still implies it for every candidate further out; W = kappa B (1 + 1e-6) + mu covers the
+// roundings of both projections.  NaN / inf (coordinates beyond float32) compare false and fall through to
+// the exact path.
+struct SweepF {
+    double ox, oy, uo;        // origin: a point of the cloud, and its projection
+    float ut, rt;             // max |u - uo| and max(|x - ox|, |y - oy|) over the target (upper bounds)
+};
+struct SweepFQuery {
+    float x, y, u;            // the query in the recentred single-precision frame
+    float e15, mu, kappa;     // 1.5 e; projection slack; 1 or sqrt(2) rounded up
+    __device__ __forceinline__ SweepFQuery(const SweepF& f, const SweepAxis& ax, int dir, double qx, double qy) {
+        x = (float)(qx - f.ox); y = (float)(qy - f.oy); u = (float)(ax.uq - f.uo);
+        e15 = 1.8e-7f * (fabsf(x) + fabsf(y) + 2.0f * f.rt) + 1e-30f;
+        mu = 2.4e-7f * (fabsf(u) + f.ut) + (float)ax.slack * 1.000001f + 1e-30f;
+        kappa = dir < 2 ? 1.0f : 1.4142137f;
+    }
+    // float32 bounds for a float64 squared-distance bound `best`: window half-width W and filter threshold T
+    __device__ __forceinline__ void bounds(double best, float& W, float& T) const {
+        const float B = __builtin_amdgcn_sqrtf((float)best) * 1.000001f + 1e-18f;
+        W = B * kappa * 1.000001f + mu;
+        const float b = B + e15;
+        T = b * b * 1.000002f;
+    }
+};
+
+typedef float sweep_v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int sweepf_row(const float4 c) { return __float_as_int(c.w); }
+
+// first position whose float32 projection image is >= u (m if none): same place as sweep_lower_bound up to
+// float32 ties, and any start is a correct start (both directions are walked until the gap rules the rest out)
+__device__ __forceinline__ int sweepf_lower_bound(const float4* sq, int m, float u) {
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sq[mid].z < u) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One round of a filtered walk: the candidates at hi (right) and lo (left), judged together on their float32
+// images with packed arithmetic (one v_pk_* instruction serves both sides).  sq[-1] and sq[m] exist (padding),
+// so a closed side may still be loaded.  Sets inr / inl (side still inside the window) and pr / pl (candidate may
+// enter the result: evaluate it exactly).
+struct SweepFRound {
+    bool inr, inl, pr, pl;
+    float4 cr, cl;
+    __device__ __forceinline__ SweepFRound(const float4* sq, int m, int lo, int hi, const SweepFQuery& fq, float W, float T) {
+        cr = sq[hi]; cl = sq[lo];
+        const sweep_v2f cz = {cr.z, -cl.z}, uu = {-fq.u, fq.u};
+        const sweep_v2f g = cz + uu;                                   // (u_right - u_q, u_q - u_left)
+        inr = hi < m && !(g.x > W);                                    // else: everything further out is farther still
+        inl = lo >= 0 && !(g.y > W);
+        const sweep_v2f cx = {cr.x, cl.x}, cy = {cr.y, cl.y};
+        const sweep_v2f dx = fq.x - cx, dy = fq.y - cy;
+        const sweep_v2f s2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+        pr = inr && !(s2.x > T);
+        pl = inl && !(s2.y > T);
+    }
+};
+
+// sweep_nn with the filter: sq = float32 images (padded by one entry at either end), sxy = exact points (read only
+// for candidates that pass)
+__device__ __forceinline__ int sweepf_nn(const float4* sq, const double2* sxy, const SweepF& f, int m, int dir, double uabs,
+                                         double qx, double qy, int seed, bool CENTRED, double& d2_out) {
+    const SweepAxis ax(dir, qx, qy, uabs);
+    const SweepFQuery fq(f, ax, dir, qx, qy);
+    double best = __builtin_inf();
+    float W = __builtin_inff(), T = __builtin_inff();
+    int bpos = 0;
+    int lo, hi;
+    const bool seeded = seed >= 0 && seed < m;
+    if (seeded) {
+        best = sweep_d2(qx, qy, sxy[seed]); bpos = seed;
+        fq.bounds(best, W, T);
+    }
+    if (seeded && !CENTRED) { lo = seed - 1; hi = seed + 1; }
+    else {
+        hi = sweepf_lower_bound(sq, m, fq.u);
+        lo = hi - 1;
+    }
+    while (lo >= 0 || hi < m) {
+        const SweepFRound r(sq, m, lo, hi, fq, W, T);
+        if (r.pr || r.pl) {                                            // might win (or tie): the exact test
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int i = side == 0 ? hi : lo;
+                if (side == 0 ? r.pr : r.pl) {
+                    const double s = sweep_d2(qx, qy, sxy[i]);
+                    if (s == best && i != bpos) {                      // exact tie: the lowest original row wins
+                        if (sweepf_row(side == 0 ? r.cr : r.cl) < sweepf_row(sq[bpos])) bpos = i;
+                    }
+                    if (s < best) { best = s; bpos = i; }
+                }
+            }
+            fq.bounds(best, W, T);
+        }
+        hi = r.inr ? hi + 1 : m;
+        lo = r.inl ? lo - 1 : -1;
+    }
+    d2_out = best;
+    return bpos;
+}
+
+// sweep_top2 with the filter (bounds from the third distance)
+__device__ __forceinline__ Top2 sweepf_top2(const float4* sq, const double2* sxy, const SweepF& f, int m, int dir, double uabs,
+                                            double qx, double qy, int seed, bool CENTRED) {
+    const SweepAxis ax(dir, qx, qy, uabs);
+    const SweepFQuery fq(f, ax, dir, qx, qy);
+    Top2 t;
+    t.p1 = 0; t.p2 = -1;
+    t.s1 = t.s2 = t.s3 = __builtin_inf();
+    float W = __builtin_inff(), T = __builtin_inff();
+    int lo, hi;
+    const bool seeded = seed >= 0 && seed < m;
+    if (seeded) { t.s1 = sweep_d2(qx, qy, sxy[seed]); t.p1 = seed; }
+    if (seeded && !CENTRED) { lo = seed - 1; hi = seed + 1; }
+    else {
+        hi = sweepf_lower_bound(sq, m, fq.u);
+        lo = hi - 1;
+    }
+    const int skip = seeded && CENTRED ? seed : -1;
+    while (lo >= 0 || hi < m) {
+        const SweepFRound r(sq, m, lo, hi, fq, W, T);
+        const bool pr = r.pr && hi != skip, pl = r.pl && lo != skip;
+        if (pr || pl) {
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int i = side == 0 ? hi : lo;
+                if (side == 0 ? pr : pl) {
+                    const double s = sweep_d2(qx, qy, sxy[i]);
+                    if (s == t.s1 || s == t.s2) {
+                        // exact tie with a kept distance: order by original row (the rule everywhere: (distance, row) ascending)
+                        const int row = sweepf_row(side == 0 ? r.cr : r.cl), r1 = sweepf_row(sq[t.p1]);
+                        const int r2 = t.p2 >= 0 ? sweepf_row(sq[t.p2]) : 0x7fffffff;
+                        if (s < t.s1 || (s == t.s1 && row < r1)) { t.s3 = t.s2; t.s2 = t.s1; t.p2 = t.p1; t.s1 = s; t.p1 = i; }
+                        else if (s < t.s2 || row < r2) { t.s3 = t.s2; t.s2 = s; t.p2 = i; }
+                        else t.s3 = s;                                 // tie with the second, lost on the row
+                    } else {
+                        const bool c1 = s < t.s1, c2 = s < t.s2, c3 = s < t.s3;
+                        t.s3 = c2 ? t.s2 : (c3 ? s : t.s3);
+                        t.s2 = c1 ? t.s1 : (c2 ? s : t.s2);
+                        t.p2 = c1 ? t.p1 : (c2 ? i : t.p2);
+                        t.s1 = c1 ? s : t.s1;
+                        t.p1 = c1 ? i : t.p1;
+                    }
+                }
+            }
+            fq.bounds(t.s3, W, T);
+        }
+        hi = r.inr ? hi + 1 : m;
+        lo = r.inl ? lo - 1 : -1;
+    }
+    return t;
+}
+
+#endif
 
 }  // namespace icpmi

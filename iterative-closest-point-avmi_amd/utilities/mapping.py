@@ -46,9 +46,14 @@ class OccupancyGrid2D:
     # ── the grid as the reference exposes it ─────────────────────────────────
     @property
     def log_odds(self):
-        """Host copy (ny, nx) float32 of the device grid. Assign to ``log_odds`` to upload a new grid."""
+        """READ-ONLY host copy (ny, nx) float32 of the device grid.
+
+        The reference's attribute is the live array; here the live grid is in HBM, so an in-place edit of
+        this copy (``grid.log_odds[...] = x``, ``np.clip(..., out=grid.log_odds)``) could not reach it and
+        raises instead of being silently lost.  ASSIGN an array (``grid.log_odds = a``) to upload one."""
         if self._host is None:
             self._host = self._grid.cpu().numpy()
+            self._host.setflags(write=False)
         return self._host
 
     @log_odds.setter

@@ -5,6 +5,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "iterative-closest-point-avmi_amd"))
 import numpy as np, torch
 from icpmi import synth, _lib
+if os.environ.get("ICPMI_LIB"):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ["ICPMI_LIB"])
 from icpmi.batch import IcpBatch, _ptr, _stream, voxel_downsample_set
 L = _lib.lib()
 kw = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)

@@ -10,4 +10,4 @@ import numpy as np, torch
 from icpmi import synth
 import bench
 r = bench.bench_raycast(torch, synth, 200, False)
-print(os.path.basename(_lib.LIB_PATH), "ms_per_scan", r["ms_per_scan"], "device", r["device_ms_per_scan"], "cells/s %.3e" % r["cells_per_sec"])
+print(os.path.basename(_lib.LIB_PATH), "ms_per_scan", r["ms_per_scan"], "device", r["device_ms_per_scan"], "cells/s %.3e" % r["cells_per_sec"], "single scan us", r["single_scan"]["us_per_scan"])
