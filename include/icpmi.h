@@ -158,6 +158,19 @@ int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, const int32
                           int32_t normal_k, double* out_normals, void* prepared, size_t prepared_bytes,
                           void* stream);
 
+/* The same, with the sort order left to the library: allow_polar != 0 lets clouds of at most 2048 rows be sorted
+ * by BEARING about the frame origin instead of along a projection, when the library estimates smaller search
+ * windows for it (a lidar scan in its sensor frame has one return per bearing, so the points within a distance B
+ * of a query lie in a wedge of a few points, while a projection slab holds every wall that crosses it).  The
+ * order only changes how fast icpmi_icp_batch searches — results are the exact nearest neighbours either way.
+ * Buffers prepared with allow_polar may only be passed to icpmi_icp_batch (icpmi_nn_prepared_batch walks
+ * projections).  Replaces no reference function: the KDTree construction of icp.py:173 is the closest analogue. */
+int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_dev, const int32_t* off_host,
+                             const int32_t* cnt_dev, const int32_t* cloud_ids, const int32_t* cloud_ids_host,
+                             int32_t n_sel, int32_t n_clouds, int32_t total_rows, int32_t max_n,
+                             int32_t normal_k, double* out_normals, void* prepared, size_t prepared_bytes,
+                             int32_t allow_polar, void* stream);
+
 /* Nearest neighbour on prepared targets (same contract as icpmi_nn_batch, same
  * answers bit for bit, icp.py:179): binary search + outward sweep on the sorted
  * copy instead of the exhaustive scan.  Target clouds of the pairs must have

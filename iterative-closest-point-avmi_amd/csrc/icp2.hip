@@ -178,7 +178,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
     double err = __builtin_inf(), prev = __builtin_inf(), delta = __builtin_inf();
     int iters = 0, status = ICPMI_ST_MAXITER;
 
-    if (N <= 0 || M <= 0 || dir < 0 || (TGT_LDS && M > a.lds_points) || N > THREADS * ICP2_SMAX) {
+    if (N <= 0 || M <= 0 || dir < 0 || (TGT_LDS && M > a.lds_points) || N > THREADS * ICP2_SMAX || (!FILT && dir >= SWEEP_POLAR)) {
         status = ICPMI_ST_EMPTY;                            // the launcher only sends pairs that fit
     } else {
         const bool use_p2l = a.method == ICPMI_POINT_TO_LINE;
@@ -194,16 +194,20 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                 if (use_p2l) lds_nrm[i] = gn[i];
             }
         if constexpr (FILT) {
-            // float32 images relative to the point in the middle of the sort order (small magnitudes)
-            const double2 o = gx[M >> 1];
-            filt.ox = o.x; filt.oy = o.y; filt.uo = proj(dir, o.x, o.y);
+            // float32 images: relative to the point in the middle of the sort order (small magnitudes), or — bearing
+            // order — to the frame origin the bearings are taken about
+            if (dir != SWEEP_POLAR) {
+                const double2 o = gx[M >> 1];
+                filt.ox = o.x; filt.oy = o.y; filt.uo = proj(dir, o.x, o.y);
+            }
             float rmax = 0.0f;
             for (int i = tid; i < M; i += THREADS) {
                 const double2 p = gx[i];
                 lds_xy[i] = p;
                 if (use_p2l) lds_nrm[i] = gn[i];
                 const float4 q = make_float4((float)(p.x - filt.ox), (float)(p.y - filt.oy),
-                                             (float)(proj(dir, p.x, p.y) - filt.uo), __int_as_float(go[i]));
+                                             (float)(dir == SWEEP_POLAR ? polar_key(p.x, p.y) : proj(dir, p.x, p.y) - filt.uo),
+                                             __int_as_float(go[i]));
                 lds_sq[i] = q;
                 rmax = fmaxf(rmax, fmaxf(fabsf(q.x), fabsf(q.y)));
             }

@@ -22,10 +22,10 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
     const double* __restrict__ pts, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
     const int32_t* __restrict__ cloud_ids, int k, double2* __restrict__ g_sxy, double2* __restrict__ g_snrm,
     int32_t* __restrict__ g_sorig, int32_t* __restrict__ g_dir, double* __restrict__ out_normals, int lds_points,
-    int split) {
+    int split, int polar) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ double dsc[8 * PREP_MAXW];
-    __shared__ int hist[4 * PREP_BINS];
+    __shared__ int hist[6 * PREP_BINS];
     // `split` workgroups share one cloud: each repeats the (cheap) axis choice and sort, then takes its
     // slice of the normal queries — small batches would otherwise leave a cloud's k-NN sweeps to one CU
     const int ci = blockIdx.x / split, part = blockIdx.x % split;
@@ -38,18 +38,19 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
     while (npad < M) npad <<= 1;
     double2* sxy = reinterpret_cast<double2*>(dyn);                                   // lds_points * 16 B
     int32_t* sorig = reinterpret_cast<int32_t*>(dyn + (size_t)lds_points * 16);       // lds_points * 4 B
+    float* sth = reinterpret_cast<float*>(dyn + (size_t)lds_points * 20);             // lds_points * 4 B: float32 bearings (polar order)
     // sort scratch (npad * 12 B): behind the sorted copy when the grid needs it afterwards, otherwise ON the sorted
     // copy (the sorted rows pass through registers) — 32 KB instead of 56 KB for ~1 500 points, so that the k-NN
     // loops of three workgroups instead of two share a CU
-    const size_t scratch_at = GRID ? (size_t)lds_points * 20 : 0;
+    const size_t scratch_at = GRID ? (size_t)lds_points * 24 : 0;
     uint64_t* keys = reinterpret_cast<uint64_t*>(dyn + scratch_at);                   // npad * 8 B
     uint32_t* rows = reinterpret_cast<uint32_t*>(dyn + scratch_at + (size_t)npad * 8);
 
     double bounds[4];
-    const int dir = choose_axis<PREP_THREADS>(P, M, dsc, hist, bounds);
-    // ── sort along the chosen axis ──────────────────────────────────────────
+    const int dir = choose_axis<PREP_THREADS>(P, M, dsc, hist, bounds, polar);
+    // ── sort along the chosen axis (or by bearing) ───────────────────────────
     for (int i = threadIdx.x; i < npad; i += PREP_THREADS) {
-        keys[i] = i < M ? f64_sortable(proj(dir, P[2 * i], P[2 * i + 1])) : ~0ull;
+        keys[i] = i < M ? f64_sortable(dir == SWEEP_POLAR ? polar_key(P[2 * i], P[2 * i + 1]) : proj(dir, P[2 * i], P[2 * i + 1])) : ~0ull;
         rows[i] = i < M ? (uint32_t)i : 0xffffffffu;
     }
     __syncthreads();
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
             const int row = my_row[u];
             const double2 p = make_double2(P[2 * row], P[2 * row + 1]);
             sxy[i] = p; sorig[i] = row;
+            if (KK > 0 && !GRID && dir == SWEEP_POLAR) sth[i] = (float)polar_key(p.x, p.y);
             if (part == 0) { o_sxy[i] = p; o_sorig[i] = row; }
         }
     }
@@ -93,7 +95,8 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
             prep_normals_grid<KK>(sxy, sorig, M, min(M, part * per), min(M, (part + 1) * per), kk, grid, o_snrm, o_rows);
         } else {
             // Many clouds: every CU is busy, the sum of the work counts, and the sweep has less of it per candidate.
-            prep_normals<KK>(sxy, sorig, M, min(M, part * per), min(M, (part + 1) * per), dir, kk, o_snrm, o_rows);
+            if (dir == SWEEP_POLAR) prep_normals_polar<KK>(sxy, sorig, sth, M, min(M, part * per), min(M, (part + 1) * per), kk, o_snrm, o_rows);
+            else prep_normals<KK>(sxy, sorig, M, min(M, part * per), min(M, (part + 1) * per), dir, kk, o_snrm, o_rows);
         }
     }
 }
@@ -122,6 +125,15 @@ extern "C" int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, 
                                      int32_t n_sel, int32_t n_clouds, int32_t total_rows, int32_t max_n,
                                      int32_t normal_k, double* out_normals, void* prepared, size_t prepared_bytes,
                                      void* stream) {
+    return icpmi_prepare_targets_ex(pts, off_dev, off_host, cnt_dev, cloud_ids, cloud_ids_host, n_sel, n_clouds, total_rows, max_n,
+                                    normal_k, out_normals, prepared, prepared_bytes, 0, stream);
+}
+
+extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_dev, const int32_t* off_host,
+                                        const int32_t* cnt_dev, const int32_t* cloud_ids, const int32_t* cloud_ids_host,
+                                        int32_t n_sel, int32_t n_clouds, int32_t total_rows, int32_t max_n,
+                                        int32_t normal_k, double* out_normals, void* prepared, size_t prepared_bytes,
+                                        int32_t allow_polar, void* stream) {
     using namespace icpmi;
     if (!pts || !off_dev || !prepared || n_sel < 0 || n_clouds < 0 || total_rows < 0 || max_n < 0) return ICPMI_ERR_ARG;
     if (normal_k > 31) return ICPMI_ERR_UNSUPPORTED;
@@ -159,8 +171,13 @@ extern "C" int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, 
     // sorted copy: 20 B per point, sized to the largest cloud (rounded to 64); sort scratch: 12 B per padded slot.
     // With ~1 500-point clouds this is 53 KB instead of 64 KB: three workgroups per CU instead of two.
     const int lds_points = (small_max + 63) / 64 * 64;
-    const size_t lds_sep = (size_t)lds_points * 20 + (size_t)npad * 12;                     // grid instantiation
-    const size_t lds_alias = (size_t)lds_points * 20 > (size_t)npad * 12 ? (size_t)lds_points * 20 : (size_t)npad * 12;
+    const size_t lds_sep = (size_t)lds_points * 24 + (size_t)npad * 12;                     // grid instantiation
+    const size_t lds_alias = (size_t)lds_points * 24 > (size_t)npad * 12 ? (size_t)lds_points * 24 : (size_t)npad * 12;
+    // bearing order (sweep.hpp, SWEEP_POLAR) only where every consumer understands it: clouds of at most 2 048 rows, on
+    // request; ICPMI_POLAR=0 never, =2 always (tests); the filter being off (ICPMI_ICP2_FILTER=0) also turns it off
+    int polar = allow_polar && small_max <= 2048 ? 1 : 0;
+    if (const char* env = getenv("ICPMI_POLAR")) polar = polar ? (env[0] == '0' ? 0 : (env[0] == '2' ? 2 : 1)) : 0;
+    if (const char* env = getenv("ICPMI_ICP2_FILTER")) polar = env[0] == '0' ? 0 : polar;
     int split = 256 / n_sel;                 // a workgroup for every CU when the batch is small
     split = split < 1 ? 1 : (split > 16 ? 16 : split);
     // k-NN search of the normals: grid for few clouds, sweep for many (see the kernel); ICPMI_PREP_KNN=grid|sweep
@@ -174,7 +191,7 @@ extern "C" int icpmi_prepare_targets(const double* pts, const int32_t* off_dev, 
                                 (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                          \
         prep_targets_kernel<KKV, G><<<n_sel * (KKV > 0 ? split : 1), PREP_THREADS, lds, st>>>(                          \
             pts, off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig, g_dir, out_normals, lds_points,         \
-            KKV > 0 ? split : 1);                                                                                       \
+            KKV > 0 ? split : 1, polar);                                                                                \
     } while (0)
 #define ICPMI_PREP_GO(KKV)                                                                                              \
     do { if (use_grid && KKV > 0) ICPMI_PREP_GO2(KKV, true); else ICPMI_PREP_GO2(KKV, false); } while (0)

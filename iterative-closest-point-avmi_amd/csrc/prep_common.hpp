@@ -13,8 +13,14 @@ constexpr int PREP_BINS = 64;
 // pay sqrt(2) because their projection gap bounds the distance only up to that factor).  All threads of the
 // workgroup call it and get the same answer.  dsc: 8 * THREADS/64 doubles, hist: 4 * PREP_BINS ints of LDS.
 // bounds (optional): min x, max x, min y, max y of the cloud.
+// polar > 0 adds a fifth candidate, the bearing about the frame origin (SWEEP_POLAR, sweep.hpp): a query at range r
+// sees a window of half-width B / r in the bearing, so a bin's points cost (points of the bin) x (sum of 1 / r over
+// the bin) / bin width — in the same unit as the projections' sum of squares / range.  1 / r is summed in fixed
+// point (integer atomics: the choice is reproducible) and capped at 1 mm, so a cloud with points at the origin
+// (no wedge there) never picks it.  polar == 2 forces it (tests).  hist: 6 * PREP_BINS ints.
 template <int THREADS>
-__device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, double* dsc, int* hist, double* bounds = nullptr) {
+__device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, double* dsc, int* hist, double* bounds = nullptr,
+                                           int polar = 0) {
     constexpr int MAXW = THREADS / ICPMI_WAVE;
     double mn[4], mx[4];
 #pragma unroll
@@ -30,7 +36,7 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
     if (l == 0)
 #pragma unroll
         for (int d = 0; d < 4; ++d) { dsc[d * MAXW + w] = mn[d]; dsc[(4 + d) * MAXW + w] = mx[d]; }
-    for (int i = threadIdx.x; i < 4 * PREP_BINS; i += THREADS) hist[i] = 0;
+    for (int i = threadIdx.x; i < (polar ? 6 : 4) * PREP_BINS; i += THREADS) hist[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -47,6 +53,14 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
             b = b < 0 ? 0 : (b >= PREP_BINS ? PREP_BINS - 1 : b);
             atomicAdd(&hist[d * PREP_BINS + b], 1);
         }
+        if (polar) {
+            int b = (int)((polar_key(x, y) + 3.141592653589793) * (PREP_BINS / 6.283185307179586));
+            b = b < 0 ? 0 : (b >= PREP_BINS ? PREP_BINS - 1 : b);
+            const double r = sqrt(x * x + y * y);
+            const double w = r > 1e-3 ? 1.0 / r : 1e3;
+            atomicAdd(&hist[4 * PREP_BINS + b], 1);
+            atomicAdd(reinterpret_cast<unsigned int*>(&hist[5 * PREP_BINS + b]), (unsigned int)(w * 1024.0));   // <= 4096 points x 1e3 x 1024 < 2^32
+        }
     }
     __syncthreads();
     if (bounds) { bounds[0] = mn[0]; bounds[1] = mx[0]; bounds[2] = mn[1]; bounds[3] = mx[1]; }
@@ -60,6 +74,13 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
         const double r = mx[d] - mn[d];
         const double cost = r > 0.0 ? (d < 2 ? 1.0 : 1.4142135623730951) * s / r : __builtin_inf();
         if (cost < bestc) { bestc = cost; dir = d; }       // integer histogram: identical in every thread
+    }
+    if (polar) {
+        double s = 0.0;
+#pragma unroll 4
+        for (int b = 0; b < PREP_BINS; ++b)
+            s += (double)hist[4 * PREP_BINS + b] * ((double)(unsigned int)hist[5 * PREP_BINS + b] * (1.0 / 1024.0));
+        if (s * (1.0 / 6.283185307179586) < bestc || polar == 2) dir = SWEEP_POLAR;
     }
     return dir;
 }
@@ -238,6 +259,69 @@ __device__ __forceinline__ void prep_normals(const double2* sxy, const int32_t* 
             hi = inr ? hi + 1 : M;
             lo = inl ? lo - 1 : -1;
             cr = nr; cl = nl;
+        }
+        emit_normal<KK>(top, kk, sxy, sorig, s, out_sorted, out_rows);
+    }
+}
+
+// The same k-NN search on a cloud sorted by bearing (SWEEP_POLAR): the window is the wedge |dth| <= asin(B / |q|) with
+// B the kk-th best distance so far, walked from the query's own position in both directions and once across the
+// seam at +-pi (sweep.hpp has the bound and its margins).  sth = float32 images of the sort keys.  Same lists, same
+// order, same normals as any other exact search.
+template <int KK>
+__device__ __forceinline__ void prep_normals_polar(const double2* sxy, const int32_t* sorig, const float* sth, int M, int s_begin, int s_end,
+                                                   int kk, double2* __restrict__ out_sorted, double* __restrict__ out_rows) {
+    for (int s = s_begin + threadIdx.x; s < s_end; s += blockDim.x) {
+        const double2 q = sxy[s];
+        const float thq = sth[s];
+        const float kw = 1.00001f / __builtin_amdgcn_sqrtf((float)(q.x * q.x + q.y * q.y));     // >= 1 / |q| (inf at the origin: no wedge)
+        TopKP<KK> top;
+        float W = __builtin_inff();
+        auto window = [&](double kth) {
+            const float t = (__builtin_amdgcn_sqrtf((float)kth) * 1.000001f + 1e-18f) * kw;
+            W = t <= 0.7f ? (t + 0.3f * t * t * t) * 1.000001f + 1e-6f : __builtin_inff();      // asin t <= t + 0.3 t^3 on [0, 0.7]
+        };
+        int lo, hi;
+        if (M >= KK) {
+            const int b0 = min(max(s - KK / 2, 0), M - KK);
+            top.init_block(sxy, sorig, b0, q);
+            window(kk == KK ? top.d[KK - 1] : top.kth(kk - 1));
+            lo = b0 - 1; hi = b0 + KK;
+        } else {
+            top.init();
+            top.push(0.0, s, sorig);
+            lo = s - 1; hi = s + 1;
+        }
+        int lo_end = -1, hi_end = M;
+        bool openr = true, openl = true;
+        float offr = 0.0f, offl = 0.0f;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            while ((openr && hi < hi_end) || (openl && lo > lo_end)) {
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const bool right = side == 0;
+                    if (right ? openr && hi < hi_end : openl && lo > lo_end) {
+                        const int i = right ? hi : lo;
+                        const float gap = right ? (sth[i] + offr) - thq : thq - (sth[i] - offl);
+                        if (gap > W) { if (right) openr = false; else openl = false; }    // everything further round is farther than the kk-th
+                        else {
+                            const double2 c = sxy[i];
+                            const double dx = q.x - c.x, dy = q.y - c.y;
+                            double d2 = 0.0;
+                            d2 += dx * dx;
+                            d2 += dy * dy;
+                            if (top.push(d2, i, sorig)) window(kk == KK ? top.d[KK - 1] : top.kth(kk - 1));
+                            if (right) ++hi; else --lo;
+                        }
+                    }
+                }
+            }
+            // one side at the end of the array, the other closed on a gap: continue across the seam up to where that one stopped
+            const bool endr = openr && hi >= hi_end, endl = openl && lo <= lo_end;
+            if (endr == endl) break;
+            if (endr) { hi_end = lo + 1; hi = 0; offr = 6.2831855f; openl = false; lo_end = lo; }
+            else { lo_end = hi - 1; lo = M - 1; offl = 6.2831855f; openr = false; hi_end = hi; }
         }
         emit_normal<KK>(top, kk, sxy, sorig, s, out_sorted, out_rows);
     }

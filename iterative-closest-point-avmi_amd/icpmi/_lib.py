@@ -57,6 +57,8 @@ _SIGS = {
     "icpmi_prepared_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "icpmi_prepare_targets": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_void_p]),
+    "icpmi_prepare_targets_ex": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 5 + [C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_int32, C.c_void_p]),
     "icpmi_nn_prepared_batch": (C.c_int, [C.c_void_p] * 6 + [C.c_int32] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_int32, C.c_void_p]),
     "icpmi_rotation_scores": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double,

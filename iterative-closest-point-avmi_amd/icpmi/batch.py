@@ -127,9 +127,9 @@ def normals_set(cs, k, cloud_ids=None, out=None, workspace=None):
         need = L.icpmi_prepared_bytes(cs.total_rows, cs.n_clouds, max_n)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, dtype=torch.uint8, device=cs.pts.device)
-        check(L.icpmi_prepare_targets(_ptr(cs.pts), _ptr(cs.off), None, _ptr(cs.cnt), _ptr(ids_t), None, n_sel,
-                                      cs.n_clouds, cs.total_rows, max_n, int(k), _ptr(out), _ptr(workspace),
-                                      workspace.numel(), _stream()), "estimate_normals_2d")
+        check(L.icpmi_prepare_targets_ex(_ptr(cs.pts), _ptr(cs.off), None, _ptr(cs.cnt), _ptr(ids_t), None, n_sel,
+                                         cs.n_clouds, cs.total_rows, max_n, int(k), _ptr(out), _ptr(workspace),
+                                         workspace.numel(), 1, _stream()), "estimate_normals_2d")
         return out
     need = L.icpmi_normals_workspace_bytes(cs.total_rows, max_n)
     if workspace is None or workspace.numel() < need:
@@ -262,12 +262,13 @@ class IcpBatch:
         st = _stream()
         voxel_downsample_set(self.raw, self.voxel_size, out=self.vox, workspace=self.vox_ws)
         if self.fast:
-            check(L.icpmi_prepare_targets(_ptr(self.vox.pts), _ptr(self.vox.off),
-                                          self.raw.off_host.ctypes.data_as(C.c_void_p), _ptr(self.vox.cnt),
-                                          _ptr(self.tgt_ids_dev), self.tgt_ids_host.ctypes.data_as(C.c_void_p),
-                                          len(self.tgt_ids), self.raw.n_clouds, self.raw.total_rows, self.max_tgt_n,
-                                          self.normal_k if self.use_p2l else -1, None, _ptr(self.prepared),
-                                          self.prepared.numel(), st), "prepare_targets")
+            # allow_polar: the sort order (a projection, or the bearing about the frame origin) is the library's choice
+            check(L.icpmi_prepare_targets_ex(_ptr(self.vox.pts), _ptr(self.vox.off),
+                                             self.raw.off_host.ctypes.data_as(C.c_void_p), _ptr(self.vox.cnt),
+                                             _ptr(self.tgt_ids_dev), self.tgt_ids_host.ctypes.data_as(C.c_void_p),
+                                             len(self.tgt_ids), self.raw.n_clouds, self.raw.total_rows, self.max_tgt_n,
+                                             self.normal_k if self.use_p2l else -1, None, _ptr(self.prepared),
+                                             self.prepared.numel(), 1, st), "prepare_targets")
         elif self.use_p2l:
             check(L.icpmi_normals_2d_batch(_ptr(self.vox.pts), _ptr(self.vox.off), _ptr(self.vox.cnt),
                                            _ptr(self.tgt_ids_dev), len(self.tgt_ids), self.raw.total_rows,

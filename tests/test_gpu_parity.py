@@ -158,6 +158,47 @@ def test_normals_grid_and_sweep_searches_agree(uicp, monkeypatch):
     monkeypatch.delenv("ICPMI_PREP_KNN")
 
 
+def test_bearing_order_gives_identical_results(uicp, monkeypatch):
+    """A prepared target may be sorted along a projection or by bearing about the frame origin (sweep.hpp, SWEEP_POLAR);
+    the library picks per cloud by estimated window size.  The order only changes how fast the exact searches run:
+    forcing either (ICPMI_POLAR=0 / 2) must give the same normals and the same registrations bit for bit — also where
+    the bearing order is a poor fit (points at and around the origin, clouds far from it, the seam at +-pi crossed
+    by a wall, duplicates, lattices)."""
+    from icpmi import batch, synth
+    rng = np.random.default_rng(21)
+    srcs, tgts = synth.loop_closure_batch(6, seed0=4400)
+    far = np.array([35.0, -20.0])
+    lattice = np.stack(np.meshgrid(np.arange(-15, 15) * 0.1, np.arange(-15, 15) * 0.1), -1).reshape(-1, 2)
+    seam = np.column_stack([np.full(400, -3.0), np.linspace(-1.0, 1.0, 400)])            # a wall across the seam at +-pi
+    pairs = [(srcs[i], tgts[i]) for i in range(6)]
+    pairs += [(srcs[0] + far, tgts[0] + far),                                             # global frame: origin far outside
+              (rng.uniform(-2, 2, (900, 2)), rng.uniform(-2, 2, (1100, 2))),               # points all around and near the origin
+              (lattice + 0.013, lattice), (seam + [0.02, 0.01], np.vstack([seam, seam[::7] + [2.0, 0.0]])),
+              (np.repeat(rng.uniform(-1, 1, (60, 2)), 4, axis=0), np.repeat(rng.uniform(-1, 1, (70, 2)), 3, axis=0))]
+    for method, extra in (("point_to_line", dict(normal_k=12)), ("point_to_point", dict(max_corr_dist=1.5))):
+        got = {}
+        for mode in ("0", "2", None):
+            if mode is None:
+                monkeypatch.delenv("ICPMI_POLAR", raising=False)
+            else:
+                monkeypatch.setenv("ICPMI_POLAR", mode)
+            b = batch.IcpBatch([p[0] for p in pairs] + [p[1] for p in pairs], np.arange(len(pairs)),
+                               np.arange(len(pairs), 2 * len(pairs)), 1e-10, 60, 0.04, method=method, **extra)
+            got[mode] = b.run().cpu().numpy().copy()
+        assert np.array_equal(got["0"], got["2"]), method
+        assert np.array_equal(got["0"], got[None]), method
+        assert (got["0"][:, 14] >= 2).all()
+    for pts in (tgts[0], tgts[0] + far, rng.uniform(-2, 2, (1100, 2)), lattice, seam):
+        nrm = {}
+        for mode in ("0", "2"):
+            monkeypatch.setenv("ICPMI_POLAR", mode)
+            monkeypatch.setenv("ICPMI_PREP_KNN", "sweep")
+            nrm[mode] = uicp.estimate_normals_2d(pts, 12)
+        assert np.array_equal(nrm["0"], nrm["2"]), len(pts)
+    monkeypatch.delenv("ICPMI_POLAR")
+    monkeypatch.delenv("ICPMI_PREP_KNN")
+
+
 def test_p2l_solve(uicp):
     z = load_golden("p2l_solve")
     R, t = uicp._point_to_line_solve_2d(z["src"], z["tgt"], z["normals"], z["idx"])
