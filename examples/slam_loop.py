@@ -11,10 +11,16 @@ end to end on a synthetic drive:
     submap:         RollingSubmap.attempt_icp: rotation search about the  slam.py:111-225, 505-536
                     predicted pose (narrow about the IMU yaw) + p2p ICP
     mapping:        OccupancyGrid2D.update_scan                           slam.py:552-557
-    loop closure:   batched ICP of the current scan against old scans;    slam.py:566-620
-                    an accepted closure adds a pose-graph edge, the graph
-                    is optimised, poses are rewritten, the submap buffer
-                    and the occupancy grid are rebuilt (replay of all scans)
+    loop closure:   every candidate is pre-aligned (rotation_search) and   slam.py:566-620
+                    registered — all candidates in ONE batch — and, as in
+                    the reference, the FIRST candidate in order whose error
+                    is below the gate is accepted: it adds a pose-graph
+                    edge, the graph is optimised, poses are rewritten, the
+                    submap buffer and the occupancy grid are rebuilt
+                    (replay of all scans)
+
+The geometry behind the loop is a `backend` (rotation_search, ICP, icp_batch, Submap, Grid, Graph): the MI355X
+drop-ins by default; the tests inject the CPU oracle there to check the whole composition scan by scan.
 
 It also writes and re-reads the drive in the reference's wire formats: lidar lines
 `timestamp_us;x1;y1;z1;x2;...` (services/lidar_service.py:5-19) and IMU lines
@@ -100,9 +106,26 @@ def pose_matrix(x, y, th):
     return np.array([[c, -s, x], [s, c, y], [0.0, 0.0, 1.0]])
 
 
-def run(n_scans=60, log_path=None, verbose=True, imu_path=None, loop=False, use_submap=True, lc_error_threshold=0.05):
+class GpuBackend:
+    """The accelerated drop-ins (the product path)."""
+    rotation_search = staticmethod(features.rotation_search)
+    ICP = staticmethod(uicp.ICP)
+    Submap = RollingSubmap
+    Grid = OccupancyGrid2D
+    Graph = PoseGraph2D
+
+    @staticmethod
+    def icp_batch(source, targets, R_init, t_init, **kw):
+        """-> (R [B,2,2], t [B,2], err [B], iterations [B]): the current scan against every candidate, one launch chain."""
+        R, t, err, info = batch.icp_batch(source, targets, R_init=R_init, t_init=t_init, **kw)
+        return R, t, err, info["iters"]
+
+
+def run(n_scans=60, log_path=None, verbose=True, imu_path=None, loop=False, use_submap=True, lc_error_threshold=0.05,
+        backend=None, max_candidates=5):
     from icpmi import submap as submap_mod
     uicp.VERBOSE = features.VERBOSE = submap_mod.VERBOSE = upg.VERBOSE = False
+    be = backend or GpuBackend
     segs = synth.maze_segments()
     truth = synth.loop_trajectory(n_scans) if loop else synth.trajectory(n_scans, step=0.18)
     scans = [synth.scan(p, 9000 + i, segs=segs) for i, p in enumerate(truth)]
@@ -118,10 +141,10 @@ def run(n_scans=60, log_path=None, verbose=True, imu_path=None, loop=False, use_
     icp_kw = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
     icp_cfg = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04)
     pose = pose_matrix(*truth[0])                       # start at the true pose; everything after is estimated
-    submap = RollingSubmap(window=40, voxel_size=0.04)
+    submap = be.Submap(window=40, voxel_size=0.04)
     history, mapper, timing = [], None, {"s2s": 0.0, "submap": 0.0, "map": 0.0, "loop": 0.0}
     closures, rejected, accepted = [], [], []
-    graph = PoseGraph2D()
+    graph = be.Graph()
     prev = None
     for i, cur in enumerate(scans):
         if prev is not None:
@@ -133,8 +156,8 @@ def run(n_scans=60, log_path=None, verbose=True, imu_path=None, loop=False, use_
                 d = imu.delta_yaw(stamps[i - 1], stamps[i])
                 R0, t0v = np.array([[np.cos(d), np.sin(d)], [-np.sin(d), np.cos(d)]]), np.zeros(2)   # prev -> cur frame
             else:
-                R0, t0v, _ = features.rotation_search(prev, cur, voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
-            r, t, err = uicp.ICP(prev, cur, R_init=R0, t_init=t0v, **icp_kw)
+                R0, t0v, _ = be.rotation_search(prev, cur, voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
+            r, t, err = be.ICP(prev, cur, R_init=R0, t_init=t0v, **icp_kw)
             if err <= 0.15:                                                   # error_reject_threshold, slam.py:485-490
                 T_inv = np.eye(3)
                 T_inv[:2, :2] = r.T
@@ -154,9 +177,9 @@ def run(n_scans=60, log_path=None, verbose=True, imu_path=None, loop=False, use_
         world = cur @ pose[:2, :2].T + pose[:2, 2]
         t0 = time.perf_counter()
         if mapper is None:                                                    # slam.py:398-408
-            mapper = OccupancyGrid2D(world[:, 0].min() - 50, world[:, 0].max() + 50, world[:, 1].min() - 50,
-                                     world[:, 1].max() + 50, resolution=0.05, p_hit=0.85, p_miss=0.42,
-                                     log_odds_min=-8.0, log_odds_max=8.0)
+            mapper = be.Grid(world[:, 0].min() - 50, world[:, 0].max() + 50, world[:, 1].min() - 50,
+                             world[:, 1].max() + 50, resolution=0.05, p_hit=0.85, p_miss=0.42,
+                             log_odds_min=-8.0, log_odds_max=8.0)
         mapper.update_scan(pose[:2, 2], world)
         timing["map"] += time.perf_counter() - t0
         submap.push(world)
@@ -165,15 +188,23 @@ def run(n_scans=60, log_path=None, verbose=True, imu_path=None, loop=False, use_
         if node > 0:
             odo_err = err if err <= 0.15 else 0.15
             graph.add_edge(node - 1, node, relative_transform_vec(history[-2][1], pose), np.eye(3) / max(odo_err, 1e-6))
-        # loop closure candidates: old scans near the current position, all registered in one batch (slam.py:566-597)
+        # loop closure candidates: old scans near the current position (slam.py:230-268), tried in order; each is
+        # pre-aligned and registered as _run_icp_pair does (slam.py:53-98) — all of them in one batch — and the FIRST
+        # whose error is below the gate wins (slam.py:582-597)
         t0 = time.perf_counter()
         if i >= 30 and i % 10 == 0:
-            cands = [k for k, (_, pk) in enumerate(history[:-20]) if np.linalg.norm(pk[:2, 2] - pose[:2, 2]) < 3.0][:16]
+            cands = [k for k, (_, pk) in enumerate(history[:-20]) if np.linalg.norm(pk[:2, 2] - pose[:2, 2]) < 3.0][:max_candidates]
             if cands:
-                R, t, err, info = batch.icp_batch(cur, [history[k][0] for k in cands], **icp_kw)
-                best = int(np.argmin(err))
-                closures.append((i, cands[best], float(err[best]), int(info["iters"][best])))
-                if err[best] < lc_error_threshold:                           # slam.py:582-620
+                pre = [be.rotation_search(cur, history[k][0], voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
+                       for k in cands]
+                R, t, err, its = be.icp_batch(cur, [history[k][0] for k in cands], np.array([p[0] for p in pre]),
+                                              np.array([p[1] for p in pre]), **icp_kw)
+                ok = np.flatnonzero(np.asarray(err) < lc_error_threshold)
+                first = int(ok[0]) if len(ok) else -1
+                shown = first if first >= 0 else int(np.argmin(err))
+                closures.append((i, cands[shown], float(err[shown]), int(its[shown])))
+                if first >= 0:                                               # slam.py:582-620
+                    best = first
                     T_lc = np.eye(3)
                     T_lc[:2, :2], T_lc[:2, 2] = R[best], t[best]              # cur -> candidate frame, so z = T_lc^-1
                     graph.add_edge(node, cands[best], pose_matrix_to_vec(np.linalg.inv(T_lc)),

@@ -191,6 +191,26 @@ int icpmi_rotation_scores(const double* src_c, int32_t n_src, const double* tgt,
                           const double* cos_sin, int32_t n_angles, double shift_x, double shift_y,
                           double* out_scores, void* stream);
 
+/* The whole correlative search on the device — utilities/features.py:198-232 (voxel filter of both clouds, their
+ * means, the coarse sweep, its arg-min, the fine sweep around the winner, its arg-min) and the sweeps of
+ * slam.py:146-159 — one chain of launches, nothing returns to the host in between.
+ * pts: n_src source rows followed by n_tgt target rows (raw clouds, (n, 2) float64).  coarse_cs: cos, sin of the
+ * n_coarse coarse angles.  fine_cs / fine_cnt: for EVERY coarse angle k the fine grid that follows when k wins
+ * (fine_cnt[k] <= max_fine angles, cos, sin at fine_cs[(k * max_fine + j) * 2]) — the grids and their cos / sin are
+ * the caller's (the reference's own NumPy expressions), so the chosen angle is the reference's bit for bit.
+ * centred != 0: the source is centred on its mean and shifted to the target's mean (features.py:205-216);
+ * else the rows are rotated as they are and shifted by (shift_x, shift_y) (slam.py:138-143).
+ * out_record (device, 12 doubles): voxel counts of source and target, mean of the source (2), shift (2), winning
+ * coarse index, its score, length of its fine grid, winning fine index, its score, reserved.  np.argmin semantics
+ * (first minimum; first NaN if any).  The voxel-filtered clouds stay in the workspace (256 bytes in: source rows,
+ * then target rows, counts as int32 at byte 16) for a following icpmi_nn_batch-style refinement. */
+size_t icpmi_rotation_search_workspace_bytes(int32_t n_src, int32_t n_tgt, int32_t n_coarse, int32_t max_fine);
+int icpmi_rotation_search(const double* pts, int32_t n_src, int32_t n_tgt, double voxel_size,
+                          const double* coarse_cs, int32_t n_coarse,
+                          const double* fine_cs, const int32_t* fine_cnt, int32_t max_fine,
+                          int32_t centred, double shift_x, double shift_y,
+                          double* out_record, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- OccupancyGrid2D, utilities/mapping.py ---------------------------------
  * world -> cell index, mapping.py:57-60,94-98: floor((w - min) / res), float64
  * IEEE division, result as int64. */
@@ -212,14 +232,14 @@ int icpmi_bresenham_cells(const int32_t* segs, const int64_t* cell_off, int32_t 
  * hits (world frame, float64).  Per cell the result equals the reference's
  * sequence: H adds of l_hit, then M adds of l_miss, each rounded to float32
  * from a float64 sum, then one clip to [lo, hi] per scan.
- * counts: workspace of icpmi_grid_workspace_bytes(ny, nx) bytes (two sets of 16
- * uint32 counter grids + bounding-box slots), zeroed once by the caller before
- * first use and owned by this grid afterwards.  With n_scans > 1, up to 16
- * consecutive scans are counted in ONE launch, each into its own counter grid,
- * and finalised together in scan order per cell (so the result is the sequential
- * one bit for bit); the count pass of a group shares its launch with the finalise
- * pass of the previous group (the other set of grids): a replay of S scans is
- * about S/16 + 1 launches.  Every call leaves the workspace all zero again.
+ * counts: workspace of icpmi_grid_workspace_bytes(ny, nx) bytes — room for four grids of uint32 counters plus
+ * bounding-box slots — zeroed once by the caller before first use and owned by this grid afterwards.  With
+ * n_scans > 1, consecutive scans are counted in ONE launch, each into its own counter region, and finalised
+ * together in scan order per cell (so the result is the sequential one bit for bit); the count pass of a group
+ * shares its launch with the finalise pass of the previous group (the other set of regions).  A region covers the
+ * box the rays stay in (icpmi_grid_update_scans_box; the whole grid otherwise), so a group holds up to 16 scans
+ * when the box is at most 1/8 of the grid and at least 2 always: a replay of S scans is about S/16 + 1 launches.
+ * Every call leaves the workspace all zero again.
  * scan_seq: ignored (kept for binary compatibility; calls are independent).
  * full_clip != 0 clips every cell of the grid on the first scan (needed only
  * when cells may lie outside [lo, hi] beforehand). */
@@ -244,6 +264,19 @@ int icpmi_grid_update_scans_band(float* log_odds, void* counts, int32_t ny, int3
                                  int32_t n_scans, double l_hit, double l_miss, double lo, double hi,
                                  int64_t scan_seq, int32_t full_clip, int32_t row_begin, int32_t row_end,
                                  void* stream);
+
+/* The same with a promise about where the rays lie: box_host = {x0, y0, x1, y1}, inclusive CELL bounds (host
+ * memory) that contain the origin cell and every hit cell of every scan of the call (Bresenham stays inside the
+ * rectangle spanned by its end points; cells outside the grid need not be covered), or NULL for "anywhere".
+ * Counters are then kept for that box only, which is what lets 16 scans be counted per launch inside a workspace
+ * of four grids (the Python class computes the box from the scans it is given).  A ray cell outside the box is
+ * not counted: the box is a contract, not a clip the reference has. */
+int icpmi_grid_update_scans_box(float* log_odds, void* counts, int32_t ny, int32_t nx,
+                                double min_x, double min_y, double resolution,
+                                const double* origins, const double* hits, const int32_t* hit_off_host,
+                                int32_t n_scans, double l_hit, double l_miss, double lo, double hi,
+                                int64_t scan_seq, int32_t full_clip, int32_t row_begin, int32_t row_end,
+                                const int32_t* box_host, void* stream);
 
 /* ── pose graph: PoseGraph2D.optimize, utilities/pose_graph.py:83-134 ──────────
  * Gauss-Newton on SE(2) over n_nodes poses [x, y, theta] (nodes: device, updated

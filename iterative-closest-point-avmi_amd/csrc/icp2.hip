@@ -52,6 +52,7 @@ struct Icp2Args {
     const double2* g_sxy;
     const double2* g_snrm;
     const int32_t* g_sorig;
+    const float* g_skey;      // float32 images of the sort key (bearing order only)
     const int32_t* g_dir;
     int lds_points;           // capacity of the LDS copy (points)
     double error_threshold;
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
         const double2* gx = a.g_sxy + a.off[tc];
         const double2* gn = a.g_snrm + a.off[tc];
         const int32_t* go = a.g_sorig + a.off[tc];
+        const float* gk = a.g_skey + a.off[tc];
         SweepF filt{0.0, 0.0, 0.0, 0.0f, 0.0f};
         if constexpr (TGT_LDS && !FILT)
             for (int i = tid; i < M; i += THREADS) {
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                 lds_xy[i] = p;
                 if (use_p2l) lds_nrm[i] = gn[i];
                 const float4 q = make_float4((float)(p.x - filt.ox), (float)(p.y - filt.oy),
-                                             (float)(dir == SWEEP_POLAR ? polar_key(p.x, p.y) : proj(dir, p.x, p.y) - filt.uo),
+                                             dir == SWEEP_POLAR ? gk[i] : (float)(proj(dir, p.x, p.y) - filt.uo),
                                              __int_as_float(go[i]));
                 lds_sq[i] = q;
                 rmax = fmaxf(rmax, fmaxf(fabsf(q.x), fabsf(q.y)));
@@ -541,7 +543,8 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     a.g_sxy = (const double2*)b;
     a.g_snrm = (const double2*)(b + (size_t)total_rows * 16);
     a.g_sorig = (const int32_t*)(b + (size_t)total_rows * 32);
-    a.g_dir = (const int32_t*)(b + (size_t)total_rows * 36);
+    a.g_skey = (const float*)(b + (size_t)total_rows * 36);
+    a.g_dir = (const int32_t*)(b + (size_t)total_rows * 40);
     a.error_threshold = p->error_threshold; a.max_corr_dist = p->max_corr_dist;
     a.max_iterations = p->max_iterations; a.method = p->method; a.has_init = p->has_init;
     const bool in_lds = max_tgt_n <= 4096;

@@ -68,7 +68,7 @@ extern "C" int icpmi_nn_prepared_batch(const double* pts, const int32_t* off_dev
     const unsigned char* b = (const unsigned char*)prepared;
     const double2* g_sxy = (const double2*)b;
     const int32_t* g_sorig = (const int32_t*)(b + (size_t)total_rows * 32);
-    const int32_t* g_dir = (const int32_t*)(b + (size_t)total_rows * 36);
+    const int32_t* g_dir = (const int32_t*)(b + (size_t)total_rows * 40);
     int cap = 64;
     while (cap < max_tgt_n) cap <<= 1;
     const size_t lds = (size_t)cap * 20;

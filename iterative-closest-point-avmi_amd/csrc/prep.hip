@@ -21,8 +21,8 @@ template <int KK, bool GRID>
 __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 16 ? 4 : 2))) void prep_targets_kernel(   // three workgroups per CU up to KK = 13, two up to 16
     const double* __restrict__ pts, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
     const int32_t* __restrict__ cloud_ids, int k, double2* __restrict__ g_sxy, double2* __restrict__ g_snrm,
-    int32_t* __restrict__ g_sorig, int32_t* __restrict__ g_dir, double* __restrict__ out_normals, int lds_points,
-    int split, int polar) {
+    int32_t* __restrict__ g_sorig, float* __restrict__ g_skey, int32_t* __restrict__ g_dir, double* __restrict__ out_normals,
+    int lds_points, int split, int polar) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ double dsc[8 * PREP_MAXW];
     __shared__ int hist[6 * PREP_BINS];
@@ -57,11 +57,14 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
     bitonic_sort_pairs(keys, rows, npad);
     double2* o_sxy = g_sxy + off[c];
     int32_t* o_sorig = g_sorig + off[c];
+    float* o_skey = g_skey + off[c];
     int my_row[PREP_MAX_POINTS / PREP_THREADS];
+    float my_key[PREP_MAX_POINTS / PREP_THREADS];          // float32 image of the sort key (the bearing: one atan2 per point in all)
 #pragma unroll
     for (int u = 0; u < PREP_MAX_POINTS / PREP_THREADS; ++u) {
         const int i = u * PREP_THREADS + (int)threadIdx.x;
         my_row[u] = i < M ? (int)rows[i] : 0;
+        my_key[u] = i < M ? (float)f64_unsortable(keys[i]) : 0.0f;
     }
     __syncthreads();                                             // the scratch may be the memory written next
 #pragma unroll
@@ -71,8 +74,8 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
             const int row = my_row[u];
             const double2 p = make_double2(P[2 * row], P[2 * row + 1]);
             sxy[i] = p; sorig[i] = row;
-            if (KK > 0 && !GRID && dir == SWEEP_POLAR) sth[i] = (float)polar_key(p.x, p.y);
-            if (part == 0) { o_sxy[i] = p; o_sorig[i] = row; }
+            if (KK > 0 && !GRID && dir == SWEEP_POLAR) sth[i] = my_key[u];
+            if (part == 0) { o_sxy[i] = p; o_sorig[i] = row; o_skey[i] = my_key[u]; }
         }
     }
     if (threadIdx.x == 0 && part == 0) g_dir[c] = dir;
@@ -109,10 +112,11 @@ int prep_big_cloud(const double* P, const int32_t* cnt_c, int n_cap, int normal_
                    int32_t* o_sorig, int32_t* dir_c, double* o_rows, void* scratch, size_t scratch_bytes, hipStream_t st);
 }
 
-// layout of a prepared-target buffer: sorted xy | sorted normals | sorted->row map | axis per cloud | scratch for
+// layout of a prepared-target buffer: sorted xy | sorted normals | sorted->row map | float32 bearings (bearing order) |
+// axis per cloud | scratch for
 // the sort of clouds above 4096 rows (max_n = rows of the largest cloud that will be prepared)
 static size_t prepared_core_bytes(int32_t total_rows, int32_t n_clouds) {
-    return (((size_t)total_rows * (16 + 16 + 4) + (size_t)n_clouds * 4) + 255) / 256 * 256 + 256;
+    return (((size_t)total_rows * (16 + 16 + 4 + 4) + (size_t)n_clouds * 4) + 255) / 256 * 256 + 256;
 }
 
 extern "C" size_t icpmi_prepared_bytes(int32_t total_rows, int32_t n_clouds, int32_t max_n) {
@@ -146,7 +150,8 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
     double2* g_sxy = (double2*)b;
     double2* g_snrm = (double2*)(b + (size_t)total_rows * 16);
     int32_t* g_sorig = (int32_t*)(b + (size_t)total_rows * 32);
-    int32_t* g_dir = (int32_t*)(b + (size_t)total_rows * 36);
+    float* g_skey = (float*)(b + (size_t)total_rows * 36);
+    int32_t* g_dir = (int32_t*)(b + (size_t)total_rows * 40);
     // clouds above the LDS capacity: one by one through global memory (prep_big.hip)
     int small_max = max_n;
     if (max_n > PREP_MAX_POINTS) {
@@ -190,7 +195,7 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
         if (hipFuncSetAttribute((const void*)prep_targets_kernel<KKV, G>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                 (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                          \
         prep_targets_kernel<KKV, G><<<n_sel * (KKV > 0 ? split : 1), PREP_THREADS, lds, st>>>(                          \
-            pts, off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig, g_dir, out_normals, lds_points,         \
+            pts, off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig, g_skey, g_dir, out_normals, lds_points, \
             KKV > 0 ? split : 1, polar);                                                                                \
     } while (0)
 #define ICPMI_PREP_GO(KKV)                                                                                              \

@@ -54,12 +54,14 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
             atomicAdd(&hist[d * PREP_BINS + b], 1);
         }
         if (polar) {
-            int b = (int)((polar_key(x, y) + 3.141592653589793) * (PREP_BINS / 6.283185307179586));
+            // an estimate only: float32 is plenty (and every thread computes the same numbers: reproducible)
+            const float xf = (float)x, yf = (float)y;
+            int b = (int)((atan2f(yf, xf) + 3.14159265f) * (PREP_BINS / 6.2831853f));
             b = b < 0 ? 0 : (b >= PREP_BINS ? PREP_BINS - 1 : b);
-            const double r = sqrt(x * x + y * y);
-            const double w = r > 1e-3 ? 1.0 / r : 1e3;
+            const float r = __builtin_amdgcn_sqrtf(xf * xf + yf * yf);
+            const float w = r > 1e-3f ? 1.0f / r : 1e3f;
             atomicAdd(&hist[4 * PREP_BINS + b], 1);
-            atomicAdd(reinterpret_cast<unsigned int*>(&hist[5 * PREP_BINS + b]), (unsigned int)(w * 1024.0));   // <= 4096 points x 1e3 x 1024 < 2^32
+            atomicAdd(reinterpret_cast<unsigned int*>(&hist[5 * PREP_BINS + b]), (unsigned int)(w * 1024.0f));   // <= 4096 points x 1e3 x 1024 < 2^32
         }
     }
     __syncthreads();

@@ -38,8 +38,12 @@ constexpr int RC_FIN_BLOCKS = ICPMI_RC_FIN_BLOCKS;
 struct GridDesc {
     int nx, ny;
     double min_x, min_y, res;
-    int wy0, wy1;             // rows [wy0, wy1) this call may write (the whole grid, or one rank's band of a sharded replay)
+    int wx0, wx1, wy0, wy1;   // cells [wx0, wx1) x [wy0, wy1) this call may write: the grid (or one rank's band of rows in a
+                              // sharded replay) cut to the box the caller says every ray stays in
+    int bx0, by0, bw;         // counter region of one scan: cell (x, y) counts at (y - by0) * bw + (x - bx0); covers the window
+    int ry0, ry1;             // the band of rows itself (a whole-band clip walks it; rays are only cut to it when it is not the grid)
 };
+__device__ __forceinline__ size_t counter_index(const GridDesc& g, int x, int y) { return (size_t)(y - g.by0) * g.bw + (x - g.bx0); }
 
 // bounding-box slot: every field grows by atomicMax and 0 means "empty"
 struct BBox {
@@ -139,12 +143,12 @@ __device__ __forceinline__ void ray_count_body(
 
     if (slot == 0) {
         // occupied cell, mapping.py:124-129
-        const bool hit_in = valid && hx >= 0 && hx < g.nx && hy >= g.wy0 && hy < g.wy1;
+        const bool hit_in = valid && hx >= g.wx0 && hx < g.wx1 && hy >= g.wy0 && hy < g.wy1;
         if ((mode & RC_DO_HITS) && hit_in)
-            atomicAdd(&counts[(size_t)hy * g.nx + hx], (mode & RC_PACKED) ? 0x10000u : 1u);
+            atomicAdd(&counts[counter_index(g, hx, hy)], (mode & RC_PACKED) ? 0x10000u : 1u);
         // bounding box of everything this beam can touch: Bresenham stays inside
         // the rectangle spanned by its end points
-        int bx0 = max(0, min(ox, hx)), bx1 = min(g.nx - 1, max(ox, hx));
+        int bx0 = max(g.wx0, min(ox, hx)), bx1 = min(g.wx1 - 1, max(ox, hx));
         int by0 = max(g.wy0, min(oy, hy)), by1 = min(g.wy1 - 1, max(oy, hy));
         const bool any = valid && bx0 <= bx1 && by0 <= by1;
         uint32_t a = any ? (uint32_t)(g.nx - bx0) : 0u, b = any ? (uint32_t)(g.ny - by0) : 0u;
@@ -167,10 +171,10 @@ __device__ __forceinline__ void ray_count_body(
     Ray ray;
     ray.init(ox, oy, hx, hy);
     int klo = 0, khi = 0;
-    const int minor_lo = ray.xmajor ? g.wy0 : 0, minor_hi = ray.xmajor ? g.wy1 : g.nx;
+    const int minor_lo = ray.xmajor ? g.wy0 : g.wx0, minor_hi = ray.xmajor ? g.wy1 : g.wx1;
     if (valid) {
-        if (ray.xmajor) ray.clip_major(0, g.nx, klo, khi); else ray.clip_major(g.wy0, g.wy1, klo, khi);
-        if (g.wy0 > 0 || g.wy1 < g.ny) ray.clip_minor(minor_lo, minor_hi, klo, khi);   // a band: skip the steps outside it
+        if (ray.xmajor) ray.clip_major(g.wx0, g.wx1, klo, khi); else ray.clip_major(g.wy0, g.wy1, klo, khi);
+        if (g.ry0 > 0 || g.ry1 < g.ny) ray.clip_minor(minor_lo, minor_hi, klo, khi);   // a band: skip the steps outside it
     }
     const int len = khi - klo;
     int lmax = len;
@@ -188,7 +192,7 @@ __device__ __forceinline__ void ray_count_body(
                 if (mn >= minor_lo && mn < minor_hi) {
                     int x, y;
                     ray.cell(k, x, y);
-                    cellid = (long long)y * g.nx + x;
+                    cellid = (long long)counter_index(g, x, y);
                 }
                 ray.step();
             }
@@ -274,7 +278,7 @@ __device__ __forceinline__ void ray_finalize_body(const GridDesc& g, const FinAr
     const int count_kind = f.count_kind, clip = f.clip, full_clip = f.full_clip;
     int x0, y0, x1, y1;
     const BBox bb = *bbox;
-    if (full_clip) { x0 = 0; y0 = g.wy0; x1 = g.nx - 1; y1 = g.wy1 - 1; }
+    if (full_clip) { x0 = 0; y0 = g.ry0; x1 = g.nx - 1; y1 = g.ry1 - 1; }        // the whole band, also outside the counted window
     else {
         if (bb.inv_x0 == 0) { x0 = 0; y0 = 0; x1 = -1; y1 = -1; }
         else { x0 = g.nx - (int)bb.inv_x0; y0 = g.ny - (int)bb.inv_y0; x1 = (int)bb.x1p - 1; y1 = (int)bb.y1p - 1; }   // inside the band by construction
@@ -282,11 +286,13 @@ __device__ __forceinline__ void ray_finalize_body(const GridDesc& g, const FinAr
     for (int y = y0 + block; y <= y1; y += nblocks)
         for (int x = x0 + threadIdx.x; x <= x1; x += RC_THREADS) {
             const size_t c = (size_t)y * g.nx + x;
+            const bool counted = x >= g.wx0 && x < g.wx1 && y >= g.wy0 && y < g.wy1;      // only a whole-band clip walks beyond the window
+            const size_t cc = counted ? counter_index(g, x, y) : 0;
             uint32_t cn[RC_GROUP_MAX];
             uint32_t any = 0;
 #pragma unroll
             for (int s = 0; s < RC_GROUP_MAX; ++s) {                 // independent loads first, then the ordered replay
-                cn[s] = s < f.n_grids ? counts[(size_t)s * f.grid_stride + c] : 0u;
+                cn[s] = counted && s < f.n_grids ? counts[(size_t)s * f.grid_stride + cc] : 0u;
                 any |= cn[s];
             }
             if (any) {
@@ -294,7 +300,7 @@ __device__ __forceinline__ void ray_finalize_body(const GridDesc& g, const FinAr
 #pragma unroll
                 for (int s = 0; s < RC_GROUP_MAX; ++s)
                     if (cn[s]) {
-                        counts[(size_t)s * f.grid_stride + c] = 0;
+                        counts[(size_t)s * f.grid_stride + cc] = 0;
                         const uint32_t H = count_kind == 0 ? cn[s] >> 16 : (count_kind == 1 ? cn[s] : 0u);
                         const uint32_t M = count_kind == 0 ? cn[s] & 0xffffu : (count_kind == 2 ? cn[s] : 0u);
                         v = apply_counts(v, H, M, l_hit, l_miss, lo32, hi32, clip != 0);
@@ -376,10 +382,14 @@ __global__ void bresenham_cells_kernel(const int32_t* __restrict__ segs, const l
 
 }  // namespace icpmi
 
-// two sets of RC_GROUP_MAX counter grids (group parity) + three bounding-box slots (group index mod 3)
+// Counter workspace: room for FOUR grids of uint32 counters (+ three bounding-box slots), whatever the group size.
+// A scan's counters cover only the box the caller says its rays stay in (icpmi_grid_update_scans_box), so two sets
+// (group parity) of up to RC_GROUP_MAX scans fit as long as the box is at most 1/8 of the grid — the usual case: a
+// lidar's reach against a map with tens of metres of margin; with larger boxes the groups shrink (two scans per
+// group for a box as large as the grid).
 extern "C" size_t icpmi_grid_workspace_bytes(int32_t ny, int32_t nx) {
     if (ny <= 0 || nx <= 0) return 0;
-    return 2 * (size_t)icpmi::RC_GROUP_MAX * (size_t)ny * (size_t)nx * sizeof(uint32_t) + 256;
+    return 4 * (size_t)ny * (size_t)nx * sizeof(uint32_t) + 256;
 }
 
 extern "C" int icpmi_world_to_grid(const double* w, int64_t n, double min_w, double resolution, int64_t* out, void* stream) {
@@ -413,20 +423,42 @@ extern "C" int icpmi_grid_update_scans_band(float* log_odds, void* counts_ws, in
                                             int32_t n_scans, double l_hit, double l_miss, double lo, double hi,
                                             int64_t scan_seq, int32_t full_clip, int32_t row_begin, int32_t row_end,
                                             void* stream) {
+    return icpmi_grid_update_scans_box(log_odds, counts_ws, ny, nx, min_x, min_y, resolution, origins, hits, hit_off_host, n_scans,
+                                       l_hit, l_miss, lo, hi, scan_seq, full_clip, row_begin, row_end, nullptr, stream);
+}
+
+extern "C" int icpmi_grid_update_scans_box(float* log_odds, void* counts_ws, int32_t ny, int32_t nx,
+                                           double min_x, double min_y, double resolution,
+                                           const double* origins, const double* hits, const int32_t* hit_off_host,
+                                           int32_t n_scans, double l_hit, double l_miss, double lo, double hi,
+                                           int64_t scan_seq, int32_t full_clip, int32_t row_begin, int32_t row_end,
+                                           const int32_t* box_host, void* stream) {
     using namespace icpmi;
     if (!log_odds || !counts_ws || !origins || !hit_off_host || ny <= 0 || nx <= 0 || n_scans < 0) return ICPMI_ERR_ARG;
     if (row_begin < 0 || row_end > ny || row_begin > row_end) return ICPMI_ERR_ARG;
     if (row_begin == row_end) return ICPMI_OK;                  // an empty band: nothing to write
     if (ny > RC_COORD_MAX || nx > RC_COORD_MAX || !(resolution > 0.0)) return ICPMI_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const size_t cells = (size_t)ny * (size_t)nx;
-    uint32_t* set2[2] = {(uint32_t*)counts_ws, (uint32_t*)counts_ws + (size_t)RC_GROUP_MAX * cells};
-    BBox* slots = (BBox*)((unsigned char*)counts_ws + 2 * (size_t)RC_GROUP_MAX * cells * sizeof(uint32_t));
+    // the window: grid (band) cut to the caller's box; one counter region per scan of a group covers it
+    int wx0 = 0, wx1 = nx, wy0 = row_begin, wy1 = row_end;
+    if (box_host) {
+        wx0 = box_host[0] > wx0 ? box_host[0] : wx0; wy0 = box_host[1] > wy0 ? box_host[1] : wy0;
+        wx1 = box_host[2] + 1 < wx1 ? box_host[2] + 1 : wx1; wy1 = box_host[3] + 1 < wy1 ? box_host[3] + 1 : wy1;
+    }
+    const bool empty_window = wx0 >= wx1 || wy0 >= wy1;             // no cell of the band can be touched (a full clip still runs)
+    if (empty_window) { wx0 = 0; wx1 = 1; wy0 = row_begin; wy1 = row_begin + 1; }
+    const size_t cells = (size_t)(wx1 - wx0) * (size_t)(wy1 - wy0);                 // counters per scan
+    const size_t capacity = 4 * (size_t)ny * (size_t)nx;
+    int group_max = (int)(capacity / (2 * cells));                                  // >= 2: the window is at most the grid
+    group_max = group_max > RC_GROUP_MAX ? RC_GROUP_MAX : group_max;
+    uint32_t* set2[2] = {(uint32_t*)counts_ws, (uint32_t*)counts_ws + (size_t)group_max * cells};
+    BBox* slots = (BBox*)((unsigned char*)counts_ws + capacity * sizeof(uint32_t));
     // every call starts with empty boxes and ends with empty counter grids (each finalise pass zeroes what it
     // reads), so calls are independent of each other; scan_seq is no longer needed and ignored
     (void)scan_seq;
     if (hipMemsetAsync(slots, 0, 3 * sizeof(BBox), st) != hipSuccess) return ICPMI_ERR_HIP;
-    GridDesc g{nx, ny, min_x, min_y, resolution, row_begin, row_end};
+    GridDesc g{nx, ny, min_x, min_y, resolution, wx0, wx1, wy0, wy1, wx0, wy0, wx1 - wx0, row_begin, row_end};
+    if (empty_window) { g.wx1 = g.wx0; }                              // nothing is counted; the finalise pass only clips
     FinArgs fin{};
     fin.log_odds = log_odds; fin.l_hit = l_hit; fin.l_miss = l_miss; fin.lo32 = (float)lo; fin.hi32 = (float)hi;
     fin.grid_stride = cells; fin.n_grids = 1;
@@ -449,7 +481,7 @@ extern "C" int icpmi_grid_update_scans_band(float* log_odds, void* counts_ws, in
             // a group: the following scans too, while they fit a 16-bit counter (empty scans are skipped over)
             ScanGroup grp{};
             int t = s;
-            while (t < n_scans && grp.n < RC_GROUP_MAX) {
+            while (t < n_scans && grp.n < group_max) {
                 const int nb = hit_off_host[t + 1] - hit_off_host[t];
                 if (nb < 0) return ICPMI_ERR_ARG;
                 if (nb > 65535) break;

@@ -555,8 +555,10 @@ __device__ __forceinline__ int sweepf_nn(const float4* sq, const double2* sxy, c
         best = sweep_d2(qx, qy, sxy[seed]); bpos = seed;
         fq.bounds(best, W, T);
     }
-    const int h0 = seeded && !CENTRED ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
-    SweepFWalk w(seeded && !CENTRED ? seed - 1 : h0 - 1, h0, m, fq.u);
+    // a seed on the other side of the seam at +-pi is no place to start from (the walk would cross the whole array)
+    const bool from_seed = seeded && !CENTRED && !(fq.polar && fabsf(sq[seed].z - fq.u) > 3.0f);
+    const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
+    SweepFWalk w(from_seed ? seed - 1 : h0 - 1, h0, m, fq.u);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         while (w.more()) {
@@ -593,8 +595,10 @@ __device__ __forceinline__ Top2 sweepf_top2(const float4* sq, const double2* sxy
     float W = __builtin_inff(), T = __builtin_inff();
     const bool seeded = seed >= 0 && seed < m;
     if (seeded) { t.s1 = sweep_d2(qx, qy, sxy[seed]); t.p1 = seed; }
-    const int h0 = seeded && !CENTRED ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
-    SweepFWalk w(seeded && !CENTRED ? seed - 1 : h0 - 1, h0, m, fq.u);
+    // a seed on the other side of the seam at +-pi is no place to start from (the walk would cross the whole array)
+    const bool from_seed = seeded && !CENTRED && !(fq.polar && fabsf(sq[seed].z - fq.u) > 3.0f);
+    const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
+    SweepFWalk w(from_seed ? seed - 1 : h0 - 1, h0, m, fq.u);
     const int skip = seeded ? seed : -1;                               // the seed is in the list already
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {

@@ -63,6 +63,10 @@ _SIGS = {
                                           C.c_int32, C.c_void_p]),
     "icpmi_rotation_scores": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double,
                                         C.c_double, C.c_void_p, C.c_void_p]),
+    "icpmi_rotation_search_workspace_bytes": (C.c_size_t, [C.c_int32] * 4),
+    "icpmi_rotation_search": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                        C.c_size_t, C.c_void_p]),
     "icpmi_world_to_grid": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "icpmi_bresenham_cells": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "icpmi_grid_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
@@ -73,6 +77,10 @@ _SIGS = {
                                                C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
                                                C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32,
                                                C.c_int32, C.c_void_p]),
+    "icpmi_grid_update_scans_box": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                              C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
+                                              C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int32, C.c_int32,
+                                              C.c_int32, C.c_void_p, C.c_void_p]),
     "icpmi_pose_graph_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
     "icpmi_pose_graph_optimize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_size_t,

@@ -301,6 +301,84 @@ def unpack_results(res, dim):
     return R, t, err, info
 
 
+class PairContext:
+    """One scan pair at a time through buffers that stay allocated (one context per device).
+
+    ``utilities.icp.ICP`` is called once per scan by a SLAM loop (slam.py:90, 217, 471); building an ``IcpBatch`` per
+    call — a dozen allocations, uploads of offsets and pair lists — cost more than its kernels.  Here the device
+    buffers are sized for a capacity (grown when a larger cloud arrives) and a call is: one pinned upload of the
+    two clouds and their offsets, the three launches of ``IcpBatch.run``, one 128-byte read-back.  2-D clouds of at
+    most 4096 rows each (the on-chip kernels); anything else builds a fresh ``IcpBatch``."""
+    _per_device = {}
+
+    @classmethod
+    def get(cls):
+        require_gpu()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if dev not in cls._per_device:
+            cls._per_device[dev] = cls(dev)
+        return cls._per_device[dev]
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.cap = 0
+        self.batch = None
+
+    def _grow(self, rows):
+        self.cap = max(4096, 2 * rows)
+        half = self.cap // 2
+        dummy = CloudSet(torch.zeros((self.cap, 2), dtype=torch.float64, device=self.dev),
+                         np.array([0, half, self.cap], dtype=np.int32))
+        self.batch = IcpBatch(dummy, [0], [1], 1e-6, 1, 1.0, np.eye(2), np.zeros(2), "point_to_line", 1, None)
+        self.stage = torch.empty((self.cap, 2), dtype=torch.float64).pin_memory()
+        self.off_stage = torch.zeros(3, dtype=torch.int32).pin_memory()
+        self.init_stage = torch.zeros((1, 6), dtype=torch.float64).pin_memory()
+        self.res_host = torch.zeros((1, _lib.RES_DOUBLES), dtype=torch.float64).pin_memory()
+
+    def solve(self, source, target, error_threshold, max_iterations, voxel_size, R_init, t_init, method, normal_k,
+              max_corr_dist):
+        """-> one (RES_DOUBLES,) float64 result record on the host."""
+        ns, nt = len(source), len(target)
+        if ns + nt > self.cap:
+            self._grow(ns + nt)
+        b = self.batch
+        h = self.stage.numpy()
+        h[:ns] = source
+        h[ns:ns + nt] = target
+        b.raw.pts[:ns + nt].copy_(self.stage[:ns + nt], non_blocking=True)
+        b.raw.off_host[:] = (0, ns, ns + nt)
+        self.off_stage.numpy()[:] = b.raw.off_host
+        b.raw.off.copy_(self.off_stage, non_blocking=True)
+        b.max_src_n, b.max_tgt_n = ns, nt
+        b.voxel_size, b.normal_k = float(voxel_size), int(normal_k)
+        use_p2l = method == "point_to_line"
+        have_init = R_init is not None and t_init is not None                    # icp.py:153
+        b.use_p2l = use_p2l
+        b.params = IcpParams(float(error_threshold), -1.0 if max_corr_dist is None else float(max_corr_dist),
+                             int(max_iterations), _lib.POINT_TO_LINE if use_p2l else _lib.POINT_TO_POINT,
+                             1 if have_init else 0, 2)
+        if have_init:
+            self.init_stage.numpy()[0, :4] = np.asarray(R_init, dtype=np.float64).reshape(4)
+            self.init_stage.numpy()[0, 4:] = np.asarray(t_init, dtype=np.float64).reshape(2)
+            b.init.copy_(self.init_stage, non_blocking=True)
+        res = b.run()
+        self.res_host.copy_(res[:1], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self.res_host.numpy()[0].copy()
+
+
+def icp_pair(source, target, error_threshold, max_iterations, voxel_size, R_init=None, t_init=None,
+             method="point_to_point", normal_k=10, max_corr_dist=None):
+    """One registration with the semantics of the reference ``ICP`` -> (R, t, err, info) like ``icp_batch``."""
+    d = source.shape[1]
+    if d == 2 and len(source) <= PREP_MAX_POINTS and len(target) <= PREP_MAX_POINTS and method in ("point_to_point", "point_to_line"):
+        res = PairContext.get().solve(source, target, error_threshold, max_iterations, voxel_size, R_init, t_init, method,
+                                      normal_k, max_corr_dist)
+        return unpack_results(res[None, :], 2)
+    return icp_batch([source], [target], error_threshold, max_iterations, voxel_size, R_init, t_init, method, normal_k,
+                     max_corr_dist)
+
+
 def icp_batch(sources, targets, error_threshold, max_iterations, voxel_size, R_init=None, t_init=None,
               method="point_to_point", normal_k=10, max_corr_dist=None, force_exhaustive=False):
     """Register sources[i] onto targets[i] for every i; same per-pair semantics as the reference ``ICP``.

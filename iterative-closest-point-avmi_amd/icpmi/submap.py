@@ -137,31 +137,49 @@ def submap_rotation_search(source_local, submap_global, predicted_pose, angle_ra
                            fine_step=0.5, voxel_size=0.3):
     """slam.py:111-183 -> (R (2,2), t (2,)).
 
-    Sweeps the rotation of the scan about the predicted pose (coarse grid, then a fine grid around the
-    winner; every grid is one kernel launch scoring all its angles), then refines the translation with one
-    nearest-neighbour step over the closest 80 % of the matches.  Angle grids, arg-min, percentile and
-    the mean stay NumPy on the host, on values the kernels produce exactly as the reference's KDTree does.
+    Sweeps the rotation of the scan about the predicted pose (coarse grid, then a fine grid around the winner) as
+    ONE chain of launches (``icpmi_rotation_search``: voxel filters, both sweeps and both arg-mins on the device,
+    one 12-double read-back), then refines the translation with one nearest-neighbour step over the closest 80 %
+    of the matches.  The angle grids are the reference's NumPy expressions (every fine grid that can follow a coarse
+    winner is tabulated up front); the percentile and the inlier mean stay NumPy on distances and indices the
+    kernels produce exactly as the reference's KDTree does — R and t are the reference's bit for bit.
     """
-    from utilities.features import rotation_scores
+    from utilities.features import _SearchContext, arange_rows
     _b.require_gpu()
     predicted_pose = np.asarray(predicted_pose, dtype=np.float64)
-    src_d = _voxel_rows(_device_rows(source_local), voxel_size)               # slam.py:125-126
-    tgt_d = _voxel_rows(_device_rows(submap_global), voxel_size)
-    if len(src_d) < 5 or len(tgt_d) < 5:                                      # slam.py:128-129
-        return predicted_pose[:2, :2], predicted_pose[:2, 2]
-    src = src_d.cpu().numpy()
+    src_in, tgt_in = _device_rows(source_local), _device_rows(submap_global)
+    if src_in.shape[0] == 0 or tgt_in.shape[0] == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")   # np.min, icp.py:119
     pred_t = predicted_pose[:2, 2]
     pred_theta = np.arctan2(predicted_pose[1, 0], predicted_pose[0, 0])
     offsets = np.deg2rad(np.arange(-angle_range, angle_range + angle_step, angle_step))    # slam.py:146-151
     angles = pred_theta + offsets
-    scores = rotation_scores(src_d, tgt_d, angles, pred_t)
-    best_angle = angles[int(np.argmin(scores))]
-    fine_lo = best_angle - np.deg2rad(angle_step)                             # slam.py:154-159
-    fine_hi = best_angle + np.deg2rad(angle_step)
-    fine_angles = np.arange(fine_lo, fine_hi, np.deg2rad(fine_step))
-    if len(fine_angles) > 0:
-        fine_scores = rotation_scores(src_d, tgt_d, fine_angles, pred_t)
-        best_angle = fine_angles[int(np.argmin(fine_scores))]
+    fine, fine_n = arange_rows(angles - np.deg2rad(angle_step), angles + np.deg2rad(angle_step),
+                               np.deg2rad(fine_step))                            # slam.py:154-156, for every possible winner
+    ctx = _SearchContext.get()
+    ns, nt = int(src_in.shape[0]), int(tgt_in.shape[0])
+    if ns + nt > ctx.cap:
+        ctx.cap = max(2 * (ns + nt), 8192)
+        ctx.stage = torch.empty((ctx.cap, 2), dtype=torch.float64).pin_memory()
+        ctx.pts = torch.empty((ctx.cap, 2), dtype=torch.float64, device=ctx.dev)
+    ctx.pts[:ns].copy_(src_in)                                                    # device to device: the submap never visits the host
+    ctx.pts[ns:ns + nt].copy_(tgt_in)
+    dtab = ctx.device_table(angles, fine, fine_n)
+    max_fine = int(fine.shape[1])
+    ws = ctx.workspace(ns, nt, len(angles), max_fine)
+    _b._lib.check(_b._lib.lib().icpmi_rotation_search(_b._ptr(ctx.pts), ns, nt, float(voxel_size), _b._ptr(dtab[0]), len(angles),
+                                                      _b._ptr(dtab[1]) if max_fine else None, _b._ptr(dtab[2]) if max_fine else None,
+                                                      max_fine, 0, float(pred_t[0]), float(pred_t[1]), _b._ptr(ctx.rec), _b._ptr(ws),
+                                                      ws.numel(), _b._stream()), "submap_rotation_search")
+    rec = ctx.rec.cpu().numpy()
+    if rec[0] < 5 or rec[1] < 5:                                              # slam.py:128-129
+        return predicted_pose[:2, :2], predicted_pose[:2, 2]
+    src_d, tgt_d = ctx.filtered_clouds(ns, nt, rec)
+    src = src_d.cpu().numpy()
+    k = int(rec[6])
+    best_angle = angles[k]
+    if int(rec[8]) > 0:                                                       # slam.py:157-159
+        best_angle = fine[k, int(rec[9])]
     correction = np.degrees(best_angle - pred_theta)
     if abs(correction) > 1.0 and VERBOSE:
         print(f"  Submap rotation correction: {correction:+.1f}°")

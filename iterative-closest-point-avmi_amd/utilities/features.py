@@ -4,9 +4,11 @@ on the MI355X.
 
 Only ``rotation_search`` (the default pre-alignment, config.yaml:34) is provided:
 about half of every non-IMU scan pair of the reference goes into its ~270
-nearest-neighbour sweeps.  Here the voxel filter and every sweep are HIP kernels
-(one launch per sweep, all angles at once); the angle grids, cos/sin and the
-arg-min stay NumPy so that they are the reference's numbers bit for bit.
+nearest-neighbour sweeps.  Here the whole search is one chain of launches
+(voxel filters, means, coarse sweep, arg-min, fine sweep, arg-min) behind
+``icpmi_rotation_search``; the angle grids and their cos/sin are computed with
+the reference's own NumPy expressions (cached on the device), so the chosen angle,
+R and t are the reference's numbers bit for bit.
 The RANSAC feature pipeline (``feature_based_alignment``) is outside the
 accelerated path (off by default, unseeded in the reference).
 """
@@ -15,7 +17,6 @@ import torch
 
 from icpmi import _lib
 from icpmi import batch as _b
-from .icp import voxel_downsample
 
 VERBOSE = True      # the reference prints one line per search
 
@@ -47,25 +48,130 @@ def rotation_scores(src_rows, target, angles, shift):
     return out.cpu().numpy()
 
 
+def arange_rows(lo, hi, step):
+    """``np.arange(lo[k], hi[k], step)`` for every k at once -> (values [K, L], lengths [K]); rows are padded with
+    their last value.  Bit for bit NumPy's own numbers: arange takes ceil((stop - start) / step) elements and fills
+    them as start + i * delta with delta = (start + step) - start."""
+    lo = np.asarray(lo, dtype=np.float64).reshape(-1)
+    hi = np.asarray(hi, dtype=np.float64).reshape(-1)
+    step = np.float64(step)
+    n = np.ceil((hi - lo) / step)
+    n = np.where(np.isfinite(n) & (n > 0), n, 0).astype(np.int64)
+    L = int(n.max()) if len(n) else 0
+    i = np.arange(L, dtype=np.float64)[None, :]
+    delta = ((lo + step) - lo)[:, None]
+    vals = lo[:, None] + i * delta
+    if L > 1:
+        vals[:, 1] = lo + step
+    if L > 0:
+        vals[:, 0] = lo
+    last = np.clip(n - 1, 0, None)
+    vals = np.where(np.arange(L)[None, :] < n[:, None], vals, vals[np.arange(len(n)), last][:, None]) if L else vals
+    return vals, n
+
+
+class _SearchContext:
+    """Device buffers and angle tables of the rotation searches, kept between calls (one per device): the scans of a
+    SLAM loop have the same size every time, and allocating, uploading offsets and reading sizes back per call cost
+    several times the kernels themselves."""
+    _per_device = {}
+
+    @classmethod
+    def get(cls):
+        _b.require_gpu()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        if dev not in cls._per_device:
+            cls._per_device[dev] = cls(dev)
+        return cls._per_device[dev]
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.cap = 0
+        self.tables = {}
+        self.rec = torch.zeros(12, dtype=torch.float64, device=dev)
+        self.rec_host = torch.zeros(12, dtype=torch.float64).pin_memory()
+        self.ws = None
+
+    def upload(self, src, tgt):
+        """source rows then target rows in one pinned staging buffer -> one asynchronous copy."""
+        n = len(src) + len(tgt)
+        if n > self.cap:
+            self.cap = max(2 * n, 8192)
+            self.stage = torch.empty((self.cap, 2), dtype=torch.float64).pin_memory()
+            self.pts = torch.empty((self.cap, 2), dtype=torch.float64, device=self.dev)
+        h = self.stage.numpy()
+        h[:len(src)] = src
+        h[len(src):n] = tgt
+        self.pts[:n].copy_(self.stage[:n], non_blocking=True)
+        return self.pts
+
+    def workspace(self, n_src, n_tgt, n_coarse, max_fine):
+        need = _lib.lib().icpmi_rotation_search_workspace_bytes(n_src, n_tgt, n_coarse, max_fine)
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(2 * need, dtype=torch.uint8, device=self.dev)
+        return self.ws
+
+    def device_table(self, coarse, fine, fine_n):
+        """cos / sin of the coarse angles and of every fine grid (features.py:214 uses np.cos / np.sin) on the device."""
+        cs = np.ascontiguousarray(np.stack([np.cos(coarse), np.sin(coarse)], axis=1))
+        fcs = np.ascontiguousarray(np.stack([np.cos(fine), np.sin(fine)], axis=2)) if fine.size else np.zeros((len(coarse), 0, 2))
+        return (torch.from_numpy(cs).to(self.dev), torch.from_numpy(fcs).to(self.dev),
+                torch.from_numpy(np.ascontiguousarray(fine_n, dtype=np.int32)).to(self.dev))
+
+    def run(self, src, tgt, voxel_size, coarse, fine, fine_n, dtab, centred, shift):
+        """-> the 12-double record on the host (one synchronisation), see include/icpmi.h icpmi_rotation_search."""
+        d_cs, d_fcs, d_fn = dtab
+        pts = self.upload(src, tgt)
+        max_fine = int(fine.shape[1]) if fine.ndim == 2 else 0
+        ws = self.workspace(len(src), len(tgt), len(coarse), max_fine)
+        _lib.check(_lib.lib().icpmi_rotation_search(_b._ptr(pts), len(src), len(tgt), float(voxel_size), _b._ptr(d_cs), len(coarse),
+                                                    _b._ptr(d_fcs) if max_fine else None, _b._ptr(d_fn) if max_fine else None,
+                                                    max_fine, 1 if centred else 0, float(shift[0]), float(shift[1]),
+                                                    _b._ptr(self.rec), _b._ptr(ws), ws.numel(), _b._stream()), "rotation_search")
+        self.rec_host.copy_(self.rec, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self.rec_host.numpy().copy()
+
+    def filtered_clouds(self, n_src, n_tgt, rec):
+        """Views of the voxel-filtered source and target the last run left in the workspace (device, no copy)."""
+        v = self.ws[256:256 + (n_src + n_tgt) * 16].view(torch.float64).reshape(-1, 2)
+        return v[:int(rec[0])], v[n_src:n_src + int(rec[1])]
+
+
+def _as_rows(a, name):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim != 2 or a.shape[1] != 2:
+        raise ValueError(f"{name} must have shape (n, 2), got {a.shape}")
+    if a.shape[0] == 0:
+        # the reference fails inside np.min of voxel_downsample on an empty array (icp.py:119)
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    return a
+
+
 def rotation_search(source, target, voxel_size=0.3, angle_step_coarse=2.0, angle_step_fine=0.2):
-    """Brute-force rotation search — features.py:165-242.  Returns (R (2,2), t (2,), score)."""
-    src = voxel_downsample(source, voxel_size)                                 # features.py:200-201
-    tgt = voxel_downsample(target, voxel_size)
-    if len(src) < 5 or len(tgt) < 5:                                           # features.py:203-204
+    """Brute-force rotation search — features.py:165-242.  Returns (R (2,2), t (2,), score).
+
+    One chain of launches on the device (voxel filters, means, coarse sweep, arg-min, fine sweep, arg-min) and one
+    12-double read-back; the angle grids, their cos / sin and the final R, t are the reference's NumPy expressions."""
+    src, tgt = _as_rows(source, "source"), _as_rows(target, "target")
+    ctx = _SearchContext.get()
+    key = ("features", float(angle_step_coarse), float(angle_step_fine))
+    if key not in ctx.tables:
+        angles_coarse = np.deg2rad(np.arange(-180, 180, angle_step_coarse))    # features.py:221
+        lo = angles_coarse - np.deg2rad(angle_step_coarse)                     # features.py:227-229, for every possible winner
+        hi = angles_coarse + np.deg2rad(angle_step_coarse)
+        fine, fine_n = arange_rows(lo, hi, np.deg2rad(angle_step_fine))
+        ctx.tables[key] = (angles_coarse, fine, fine_n, ctx.device_table(angles_coarse, fine, fine_n))
+    angles_coarse, fine, fine_n, dtab = ctx.tables[key]
+    rec = ctx.run(src, tgt, voxel_size, angles_coarse, fine, fine_n, dtab, True, (0.0, 0.0))
+    if rec[0] < 5 or rec[1] < 5:                                               # features.py:203-204
         return np.eye(2), np.zeros(2), float("inf")
-    mu_s = src.mean(axis=0)
-    mu_t = tgt.mean(axis=0)
-    src_c = src - mu_s
-    angles_coarse = np.deg2rad(np.arange(-180, 180, angle_step_coarse))        # features.py:221
-    scores_coarse = rotation_scores(src_c, tgt, angles_coarse, mu_t)
-    best_angle = angles_coarse[int(np.argmin(scores_coarse))]
-    lo = best_angle - np.deg2rad(angle_step_coarse)                            # features.py:227-229
-    hi = best_angle + np.deg2rad(angle_step_coarse)
-    angles_fine = np.arange(lo, hi, np.deg2rad(angle_step_fine))
-    scores_fine = rotation_scores(src_c, tgt, angles_fine, mu_t)
-    best_f = int(np.argmin(scores_fine))
-    best_angle = angles_fine[best_f]
-    best_score = scores_fine[best_f]
+    k = int(rec[6])
+    if int(rec[8]) <= 0:
+        raise ValueError("attempt to get argmin of an empty sequence")         # np.argmin(scores_fine) on an empty grid
+    best_angle = fine[k, int(rec[9])]
+    best_score = np.float64(rec[10])
+    mu_s, mu_t = rec[2:4].copy(), rec[4:6].copy()
     ca, sa = np.cos(best_angle), np.sin(best_angle)
     R = np.array([[ca, -sa], [sa, ca]])
     t = mu_t - R @ mu_s

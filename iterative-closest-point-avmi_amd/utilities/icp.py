@@ -117,8 +117,8 @@ def ICP(source, target, error_threshold, max_iterations, voxel_size,
         raise ValueError("source and target differ in dimensionality")
     if len(source) == 0 or len(target) == 0:
         raise ValueError("zero-size array to reduction operation minimum which has no identity")
-    R, t, err, info = _b.icp_batch([source], [target], error_threshold, max_iterations, voxel_size,
-                                   R_init, t_init, method, normal_k, max_corr_dist)
+    R, t, err, info = _b.icp_pair(source, target, error_threshold, max_iterations, voxel_size,
+                                  R_init, t_init, method, normal_k, max_corr_dist)
     return R[0], t[0], _report(err[0], info, 0, max_iterations)
 
 

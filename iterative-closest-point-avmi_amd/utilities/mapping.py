@@ -36,8 +36,7 @@ class OccupancyGrid2D:
         self.log_odds_max = float(log_odds_max)
         self._dev = torch.device("cuda", torch.cuda.current_device())
         self._grid = torch.zeros((self.ny, self.nx), dtype=torch.float32, device=self._dev)
-        self._ws = torch.zeros(_lib.lib().icpmi_grid_workspace_bytes(self.ny, self.nx), dtype=torch.uint8,
-                               device=self._dev)
+        self._ws = None                    # counter workspace (four grids of uint32): allocated by the first update
         self._seq = 0                      # non-empty scans applied so far (selects counter grid / box slot)
         self._host = None                  # cached host copy of the grid
         self._full_clip = not (self.log_odds_min <= 0.0 <= self.log_odds_max)
@@ -130,26 +129,54 @@ class OccupancyGrid2D:
         sizes = [int(h.shape[0]) for h in hits]
         off = np.zeros(S + 1, dtype=np.int32)
         np.cumsum(sizes, out=off[1:])
+        box = None
         if all(isinstance(h, torch.Tensor) for h in hits):
             packed = torch.cat([h.to(self._dev, torch.float64).reshape(-1, 2) for h in hits]) if off[-1] else None
         else:
             host = np.concatenate([np.asarray(h, dtype=np.float64).reshape(-1, 2) for h in hits]) if off[-1] else None
             packed = torch.from_numpy(np.ascontiguousarray(host)).to(self._dev) if host is not None else None
-        self._apply(org, packed, off, rows)
+            if host is not None and not isinstance(origins, torch.Tensor):       # everything is on the host: no read-back
+                both = np.vstack([np.asarray(origins, dtype=np.float64).reshape(S, 2), host])
+                box = self._box_of(both.min(axis=0), both.max(axis=0))
+        self._apply(org, packed, off, rows, box)
 
-    def _apply(self, org, packed, off, rows=None):
-        """org (S,2) and packed hits (sum N,2) are float64 device tensors; off is a host int32 array."""
+    def _cell_box(self, org, packed):
+        """Inclusive cell bounds {x0, y0, x1, y1} of the origins and hits (host int32[4]): every ray stays inside
+        (Bresenham never leaves the rectangle of its end points).  Device tensors cost one small read-back."""
+        if packed is None or packed.numel() == 0:
+            return None
+        pts = torch.cat([org.reshape(-1, 2), packed.reshape(-1, 2)])
+        lo_hi = torch.stack([pts.amin(dim=0), pts.amax(dim=0)]).cpu().numpy()
+        return self._box_of(lo_hi[0], lo_hi[1])
+
+    def _box_of(self, lo, hi):
+        lo_hi = np.array([lo, hi], dtype=np.float64)
+        if not np.isfinite(lo_hi).all():
+            return None                                         # a NaN / inf coordinate somewhere: no promise
+        mn = np.array([self.min_x, self.min_y])
+        c = np.floor((lo_hi - mn) / self.resolution)            # same expression as the cell index, monotone in the coordinate
+        c = np.clip(c, -2.0 ** 29, 2.0 ** 29)
+        return np.array([c[0, 0] - 1, c[0, 1] - 1, c[1, 0] + 1, c[1, 1] + 1], dtype=np.int32)
+
+    def _apply(self, org, packed, off, rows=None, box=None):
+        """org (S,2) and packed hits (sum N,2) are float64 device tensors; off is a host int32 array.
+        box: int32[4] cell bounds of all rays (``_cell_box``), computed here when not given."""
         L = _lib.lib()
         S = len(off) - 1
         r0, r1 = (0, self.ny) if rows is None else (int(rows[0]), int(rows[1]))
         if not 0 <= r0 <= r1 <= self.ny:
             raise ValueError("rows must satisfy 0 <= begin <= end <= ny")
-        _lib.check(L.icpmi_grid_update_scans_band(_b._ptr(self._grid), _b._ptr(self._ws), self.ny, self.nx,
-                                                  self.min_x, self.min_y, self.resolution, _b._ptr(org),
-                                                  _b._ptr(packed), off.ctypes.data_as(C.c_void_p), S,
-                                                  float(self.l_hit), float(self.l_miss), self.log_odds_min,
-                                                  self.log_odds_max, self._seq, 1 if self._full_clip else 0,
-                                                  r0, r1, _b._stream()), "update_scan")
+        if self._ws is None:
+            self._ws = torch.zeros(L.icpmi_grid_workspace_bytes(self.ny, self.nx), dtype=torch.uint8, device=self._dev)
+        if box is None:
+            box = self._cell_box(org, packed)
+        _lib.check(L.icpmi_grid_update_scans_box(_b._ptr(self._grid), _b._ptr(self._ws), self.ny, self.nx,
+                                                 self.min_x, self.min_y, self.resolution, _b._ptr(org),
+                                                 _b._ptr(packed), off.ctypes.data_as(C.c_void_p), S,
+                                                 float(self.l_hit), float(self.l_miss), self.log_odds_min,
+                                                 self.log_odds_max, self._seq, 1 if self._full_clip else 0,
+                                                 r0, r1, box.ctypes.data_as(C.c_void_p) if box is not None else None,
+                                                 _b._stream()), "update_scan")
         applied = int(np.count_nonzero(np.diff(off)))
         if r1 > r0:
             self._seq += applied

@@ -93,3 +93,105 @@ def test_slam_loop_closes_the_loop():
         for pts, T in out["history"]:
             ref.update_scan(T[:2, 2], pts @ T[:2, :2].T + T[:2, 2])
         assert np.array_equal(ref.log_odds, mp.log_odds)
+
+
+# ── oracle twin of the loop: the same decisions with the CPU oracle behind every geometric call ──
+def _oracle_backend():
+    """Test infrastructure: the CPU oracle behind the harness' backend interface (never part of the product)."""
+    import oracle
+    from oracle import pose_graph as opg
+
+    class Submap:
+        def __init__(self, window=40, voxel_size=0.04):
+            self.window, self.voxel_size, self.scans = window, voxel_size, []
+
+        def __len__(self):
+            return len(self.scans)
+
+        def push(self, pts):
+            self.scans.append(np.array(pts, dtype=np.float64))
+            if len(self.scans) > self.window:
+                self.scans.pop(0)
+
+        def reset(self, scans=()):
+            self.scans = [np.array(s, dtype=np.float64) for s in list(scans)[-self.window:]]
+
+        def attempt_icp(self, source, pose, imu_yaw, imu_narrow, rot_range, rot_step, rot_fine, rot_voxel, icp_cfg, corr):
+            sub = oracle.voxel_downsample(np.vstack(self.scans), self.voxel_size)          # _build_submap, slam.py:103-108
+            r, t, e, _ = oracle.attempt_submap_icp(source, sub, pose, imu_yaw, imu_narrow, rot_range, rot_step, rot_fine,
+                                                   rot_voxel, icp_cfg, corr)
+            return r, t, e
+
+    class Grid:
+        def __init__(self, min_x, max_x, min_y, max_y, resolution, p_hit, p_miss, log_odds_min, log_odds_max):
+            self.min_x, self.max_x, self.min_y, self.max_y, self.resolution = min_x, max_x, min_y, max_y, resolution
+            self.nx = int(np.ceil((max_x - min_x) / resolution))
+            self.ny = int(np.ceil((max_y - min_y) / resolution))
+            self.l_hit, self.l_miss = np.log(p_hit / (1 - p_hit)), np.log(p_miss / (1 - p_miss))
+            self.lo, self.hi = log_odds_min, log_odds_max
+            self.log_odds = np.zeros((self.ny, self.nx), dtype=np.float32)
+
+        def update_scan(self, origin, hits):
+            oracle.grid_update_scan(self.log_odds, self.min_x, self.min_y, self.resolution, origin, hits, self.l_hit, self.l_miss,
+                                    self.lo, self.hi)
+
+        def update_scans(self, origins, hits):
+            for o, h in zip(origins, hits):
+                self.update_scan(o, h)
+
+        def reset(self):
+            self.log_odds[:] = 0.0
+
+    class Graph:
+        def __init__(self):
+            self.nodes, self.edges, self.last_info = [], [], {}
+
+        def add_node(self, v):
+            self.nodes.append(np.asarray(v, dtype=float).copy())
+            return len(self.nodes) - 1
+
+        def add_edge(self, i, j, z, omega=None):
+            self.edges.append((i, j, np.asarray(z, dtype=float), np.eye(3) if omega is None else np.asarray(omega, dtype=float)))
+
+        def optimize(self, n_iterations=20, fix_node=0, convergence_eps=1e-6):
+            ei, ej = [e[0] for e in self.edges], [e[1] for e in self.edges]
+            nodes, it, st, step = opg.optimize(np.array(self.nodes), ei, ej, np.array([e[2] for e in self.edges]),
+                                               np.array([e[3] for e in self.edges]), n_iterations, fix_node, convergence_eps)
+            self.nodes = [v.copy() for v in nodes]
+            self.last_info = dict(iterations=it, status=st, step=step)
+
+    class Backend:
+        rotation_search = staticmethod(oracle.rotation_search)
+
+        @staticmethod
+        def ICP(s, t, **kw):
+            return oracle.icp(s, t, **kw)[:3]
+
+        @staticmethod
+        def icp_batch(source, targets, R_init, t_init, **kw):
+            out = [oracle.icp(source, tg, R_init=R_init[k], t_init=t_init[k], **kw) for k, tg in enumerate(targets)]
+            return (np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out]),
+                    np.array([o[3]["iters"] for o in out]))
+
+    Backend.Submap, Backend.Grid, Backend.Graph = Submap, Grid, Graph
+    return Backend
+
+
+@pytest.mark.gpu
+def test_slam_loop_equals_its_oracle_twin():
+    """The composed per-scan pipeline (slam.py:466-620: scan-to-scan ICP -> submap attempt -> map update -> closure
+    candidates, first accepted -> pose graph -> pose rewrite -> submap and map rebuild) run twice on the same synthetic
+    circuit: on the MI355X drop-ins and with the CPU oracle behind every geometric call.  Same decisions (rejections,
+    closure candidates tried, closures accepted), poses within 1e-6, final occupancy grid bit for bit."""
+    m = _load()
+    n = 41                                                            # closure checks at scans 30 and 40
+    gpu = m.run(n, verbose=False, loop=True)
+    ref = m.run(n, verbose=False, loop=True, backend=_oracle_backend())
+    assert gpu["rejected"] == ref["rejected"]
+    assert [c[:2] for c in gpu["closures"]] == [c[:2] for c in ref["closures"]] and len(gpu["closures"]) >= 1
+    assert [c[3] for c in gpu["closures"]] == [c[3] for c in ref["closures"]]           # same iteration counts
+    assert np.allclose([c[2] for c in gpu["closures"]], [c[2] for c in ref["closures"]], rtol=0, atol=1e-9)
+    assert [a[:2] for a in gpu["accepted"]] == [a[:2] for a in ref["accepted"]]
+    for (_, Tg), (_, Tr) in zip(gpu["history"], ref["history"]):
+        assert np.abs(Tg - Tr).max() < 1e-6
+    assert np.array_equal(gpu["mapper"].log_odds, ref["mapper"].log_odds)

@@ -3,6 +3,8 @@
 
   by-grid table:   python tools/profile_summary.py trace <dir>/<prefix>_kernel_trace.csv > profiles/rNN_bench_by_grid.md
   PMC traffic:     python tools/profile_summary.py pmc <fetch>_counter_collection.csv <write>_counter_collection.csv > profiles/rNN_pmc_traffic.json
+                   (records the signature of the kernel sources, bench.csrc_signature(): bench.py quotes the summary as
+                   `roofline.traffic` only while the library it runs was built from the same sources)
 
 The PMC passes are separate rocprofv3 runs (`--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`, each with --kernel-trace only).
 Counters are KiB per dispatch; FETCH_SIZE is doubled for the 16-B-per-lane coalesced reads of these kernels, as
@@ -45,10 +47,20 @@ def pmc(fetch_csv, write_csv):
         return {k: sum(v) / len(v) for k, v in acc.items()}
 
     fe, wr = collect(fetch_csv, "FETCH_SIZE"), collect(write_csv, "WRITE_SIZE")
+    import os
+    import subprocess
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    try:
+        commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                                cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+    except OSError:
+        commit = ""
     out = {"how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python3 bench.py "
-                  "--steps 5 --warmup 1 --no-cpu-baseline --no-raycast; counters are KiB per dispatch, averaged over the "
+                  "--steps 5 --warmup 1 --no-cpu-baseline; counters are KiB per dispatch, averaged over the "
                   "dispatches of a kernel at one grid size; FETCH_SIZE doubled for 16-B-per-lane coalesced reads as "
                   "MI355X_MICROARCH.md (HBM) prescribes; WRITE_SIZE as read",
+           "csrc_sha256": bench.csrc_signature(), "summarised_at_commit": commit,
            "kernels": {}}
     for k in sorted(set(fe) & set(wr)):
         out["kernels"][k] = {"FETCH_SIZE_KiB": round(fe[k], 1), "WRITE_SIZE_KiB": round(wr[k], 1),
