@@ -283,47 +283,44 @@ __device__ __forceinline__ void prep_normals_polar(const double2* sxy, const int
             const float t = (__builtin_amdgcn_sqrtf((float)kth) * 1.000001f + 1e-18f) * kw;
             W = t <= 0.7f ? (t + 0.3f * t * t * t) * 1.000001f + 1e-6f : __builtin_inff();      // asin t <= t + 0.3 t^3 on [0, 0.7]
         };
-        int lo, hi;
+        int lo, hi, remaining;                                       // remaining: positions not yet looked at
         if (M >= KK) {
             const int b0 = min(max(s - KK / 2, 0), M - KK);
             top.init_block(sxy, sorig, b0, q);
             window(kk == KK ? top.d[KK - 1] : top.kth(kk - 1));
-            lo = b0 - 1; hi = b0 + KK;
+            lo = b0 - 1; hi = b0 + KK; remaining = M - KK;
         } else {
             top.init();
             top.push(0.0, s, sorig);
-            lo = s - 1; hi = s + 1;
+            lo = s - 1; hi = s + 1; remaining = M - 1;
         }
-        int lo_end = -1, hi_end = M;
-        bool openr = true, openl = true;
+        // The array is a circle: a side that runs off its end continues at the other one with its bearings shifted by
+        // 2 pi (a query next to the seam at +-pi has half of its neighbours there, and until they are seen the bound —
+        // hence the window — may be as wide as the whole cloud).  `remaining` stops the two sides where they meet.
         float offr = 0.0f, offl = 0.0f;
-#pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            while ((openr && hi < hi_end) || (openl && lo > lo_end)) {
-#pragma unroll
-                for (int side = 0; side < 2; ++side) {
-                    const bool right = side == 0;
-                    if (right ? openr && hi < hi_end : openl && lo > lo_end) {
-                        const int i = right ? hi : lo;
-                        const float gap = right ? (sth[i] + offr) - thq : thq - (sth[i] - offl);
-                        if (gap > W) { if (right) openr = false; else openl = false; }    // everything further round is farther than the kk-th
-                        else {
-                            const double2 c = sxy[i];
-                            const double dx = q.x - c.x, dy = q.y - c.y;
-                            double d2 = 0.0;
-                            d2 += dx * dx;
-                            d2 += dy * dy;
-                            if (top.push(d2, i, sorig)) window(kk == KK ? top.d[KK - 1] : top.kth(kk - 1));
-                            if (right) ++hi; else --lo;
-                        }
-                    }
-                }
-            }
-            // one side at the end of the array, the other closed on a gap: continue across the seam up to where that one stopped
-            const bool endr = openr && hi >= hi_end, endl = openl && lo <= lo_end;
-            if (endr == endl) break;
-            if (endr) { hi_end = lo + 1; hi = 0; offr = 6.2831855f; openl = false; lo_end = lo; }
-            else { lo_end = hi - 1; lo = M - 1; offl = 6.2831855f; openr = false; hi_end = hi; }
+        if (hi >= M) { hi -= M; offr = 6.2831855f; }
+        if (lo < 0) { lo += M; offl = 6.2831855f; }
+        bool openr = true, openl = true;
+        // one candidate from each open side per round; bearings and points of both are loaded before either is used and
+        // the next pair is fetched meanwhile
+        float tr = sth[hi], tl = sth[lo];
+        double2 cr = sxy[hi], cl = sxy[lo];
+        while ((openr || openl) && remaining > 0) {
+            const int nh = hi + 1 == M ? 0 : hi + 1, nl = lo == 0 ? M - 1 : lo - 1;
+            const float ntr = sth[nh], ntl = sth[nl];
+            const double2 ncr = sxy[nh], ncl = sxy[nl];
+            const bool inr = openr && !((tr + offr) - thq > W);             // else: everything further round is farther than the kk-th
+            bool inl = openl && !(thq - (tl - offl) > W);
+            if (inr && inl && remaining == 1) inl = false;                   // both sides at the last position
+            const double sr = sweep_d2(q.x, q.y, cr), sl = sweep_d2(q.x, q.y, cl);
+            bool changed = false;
+            if (inr) changed = top.push(sr, hi, sorig);
+            if (inl) changed = top.push(sl, lo, sorig) || changed;
+            if (changed) window(kk == KK ? top.d[KK - 1] : top.kth(kk - 1));
+            openr = inr; openl = inl;
+            remaining -= (inr ? 1 : 0) + (inl ? 1 : 0);
+            if (inr) { if (nh == 0) offr = 6.2831855f; hi = nh; tr = ntr; cr = ncr; }
+            if (inl) { if (lo == 0) offl = 6.2831855f; lo = nl; tl = ntl; cl = ncl; }
         }
         emit_normal<KK>(top, kk, sxy, sorig, s, out_sorted, out_rows);
     }

@@ -88,11 +88,12 @@ def test_slam_loop_closes_the_loop():
     ref = OccupancyGrid2D(mp.min_x, mp.max_x, mp.min_y, mp.max_y, resolution=0.05, p_hit=0.85, p_miss=0.42,
                           log_odds_min=-8.0, log_odds_max=8.0)
     assert (ref.ny, ref.nx) == (mp.ny, mp.nx)
-    assert last == 80, out["accepted"]                                # closed on the last scan: nothing was added after the rebuild
-    if last == 80:
-        for pts, T in out["history"]:
-            ref.update_scan(T[:2, 2], pts @ T[:2, :2].T + T[:2, 2])
-        assert np.array_equal(ref.log_odds, mp.log_odds)
+    # the map was rebuilt at the last closure (scans 0..last at their corrected poses, in order) and scans after it
+    # were added one by one at poses nothing rewrote since: the same as every scan of the history replayed in order
+    assert 30 <= last <= 80, out["accepted"]
+    for pts, T in out["history"]:
+        ref.update_scan(T[:2, 2], pts @ T[:2, :2].T + T[:2, 2])
+    assert np.array_equal(ref.log_odds, mp.log_odds)
 
 
 # ── oracle twin of the loop: the same decisions with the CPU oracle behind every geometric call ──

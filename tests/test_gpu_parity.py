@@ -865,9 +865,10 @@ def test_pose_graph_edge_cases(uicp, capsys):
 
 
 def test_large_batch_uses_two_workgroups_per_cu_and_matches_the_oracle(uicp):
-    """From 1 024 pairs on the launcher runs 512 threads x 4 rows (two workgroups per CU); the voxel filter and the
-    prepare kernel change their occupancy too.  Same results: a sample of the pairs against the oracle, and the
-    whole batch against the same pairs run in small batches (1 024 threads x 2 rows)."""
+    """From 1 024 pairs on the launcher runs 512 threads x 3 rows (two workgroups per CU; clouds that keep more than
+    1 536 rows after the voxel filter go to a second launch of 1 024 threads); the voxel filter and the prepare kernel
+    change their occupancy too.  Same results: a sample of the pairs against the oracle, and the whole batch against
+    the same pairs run in small batches (1 024 threads x 2 rows)."""
     from icpmi import batch, synth
     B = 1100
     srcs, tgts = synth.loop_closure_batch(B, seed0=31000)
@@ -887,6 +888,37 @@ def test_large_batch_uses_two_workgroups_per_cu_and_matches_the_oracle(uicp):
         Rs, ts, es, infs = small.unpack()
         assert np.array_equal(infs["iters"], info["iters"][idx])
         assert max(rot_err(Rs[j], ts[j], R[i], t[i]) for j, i in enumerate(idx)) < 1e-11
+
+
+def test_large_batch_with_wide_clouds_takes_the_second_launch(uicp):
+    """In a large batch the fused ICP kernel holds at most 1 536 rows of a cloud (512 threads x 3 rows, LDS copy of the
+    target for two workgroups per CU).  The voxel filter leaves its row counts on the device, so the launcher cannot
+    know: pairs with a larger source OR target are skipped by the first launch and registered by a second one
+    (1 024 threads).  Mixed batch — narrow pairs, wide sources, wide targets — against the same pairs in small batches."""
+    from icpmi import batch, synth
+    B = 1040
+    srcs, tgts = synth.loop_closure_batch(B, seed0=52000)
+    for i in range(B):                              # voxel 0.005 keeps (nearly) every beam: 2 048 rows wide, 1 024 narrow
+        if i % 4 != 1:
+            srcs[i] = srcs[i][::2]
+        if i % 4 != 2:
+            tgts[i] = tgts[i][::2]
+    kw = dict(error_threshold=1e-10, max_iterations=25, voxel_size=0.005, method="point_to_line", normal_k=12)
+    big = batch.IcpBatch(srcs + tgts, np.arange(B), np.arange(B, 2 * B), **kw)
+    res = big.run().cpu().numpy()
+    cnt = big.vox.cnt.cpu().numpy()
+    assert (cnt[:B] > 1536).sum() > 200 and (cnt[B:] > 1536).sum() > 200 and ((cnt[:B] <= 1536) & (cnt[B:] <= 1536)).sum() > 200
+    assert (res[:, 15] != 4).all() and (res[:, 14] >= 2).all()             # every pair was registered by exactly one launch
+    for lo in range(0, B, 260):
+        idx = np.arange(lo, min(B, lo + 260))
+        small = batch.IcpBatch([srcs[i] for i in idx] + [tgts[i] for i in idx], np.arange(len(idx)),
+                               np.arange(len(idx), 2 * len(idx)), **kw)
+        rs = small.run().cpu().numpy()
+        assert np.array_equal(rs[:, 14], res[idx, 14])
+        assert np.abs(rs[:, :12] - res[idx, :12]).max() < 1e-11
+    for i in (1, 2, 3, 1001, 1002):
+        Ro, to, eo, io = oracle.icp(srcs[i], tgts[i], 1e-10, 25, 0.005, method="point_to_line", normal_k=12)
+        assert int(res[i, 14]) == io["iters"] and rot_err(res[i, :4].reshape(2, 2), res[i, 9:11], Ro, to) < FRO_TOL
 
 
 def test_voxel_all_three_sort_paths(uicp):

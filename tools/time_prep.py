@@ -23,8 +23,8 @@ for B in Bs:
     b = IcpBatch(srcs[:B] + tgts[:B], np.arange(B), np.arange(B, 2 * B), **kw)
     b.run(); torch.cuda.synchronize()
     def prep(k):
-        _lib.check(L.icpmi_prepare_targets(_ptr(b.vox.pts), _ptr(b.vox.off), None, _ptr(b.vox.cnt), _ptr(b.tgt_ids_dev), None,
+        _lib.check(L.icpmi_prepare_targets_ex(_ptr(b.vox.pts), _ptr(b.vox.off), None, _ptr(b.vox.cnt), _ptr(b.tgt_ids_dev), None,
                    len(b.tgt_ids), b.raw.n_clouds, b.raw.total_rows, b.max_tgt_n, k, None, _ptr(b.prepared), b.prepared.numel(),
-                   _stream()), "prep")
+                   1, _stream()), "prep")     # sort order as IcpBatch.run asks for it (ICPMI_POLAR=0: projections only)
     print(f"B={B}: voxel {timed(lambda: voxel_downsample_set(b.raw, 0.04, out=b.vox, workspace=b.vox_ws)):.3f} ms  "
           f"prep(no normals) {timed(lambda: prep(-1)):.3f} ms  prep(k=5) {timed(lambda: prep(5)):.3f} ms  prep(k=12) {timed(lambda: prep(12)):.3f} ms")
