@@ -142,8 +142,9 @@ int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const int32_t* cn
  * or x-y) with the smallest expected search window, sort the cloud along it and
  * store the sorted points, the sorted->row map and the axis in `prepared`
  * (icpmi_prepared_bytes(total_rows, n_clouds) bytes).  normal_k >= 0 also
- * computes estimate_normals_2d (icp.py:51-76) with k = normal_k: stored in
- * sorted order inside `prepared`, and in row order in out_normals if given.
+ * computes estimate_normals_2d (icp.py:51-76) with k = normal_k (any k for clouds of
+ * at most 4096 rows; k <= 31 on larger ones): stored in sorted order inside
+ * `prepared`, and in row order in out_normals if given.
  * normal_k < 0 skips normals (point_to_point).
  *
  * Clouds above 4096 rows (a rolling submap) are prepared through global memory

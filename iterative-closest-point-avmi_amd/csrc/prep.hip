@@ -104,6 +104,80 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
     }
 }
 
+
+// estimate_normals_2d for ANY k (the reference accepts every k, icp.py:61; the register lists above stop at 31):
+// one wave per query on the sorted copy in global memory.  The k + 1 nearest are drawn one after the other — each
+// round every lane scans its share of the cloud for the smallest (distance, row) beyond the last one drawn, and a
+// wave reduction picks the overall next — so the neighbours come out in the (distance, row) order every other path
+// sums them in: same lists, same arithmetic, same normals.  O(k M / 64) per query: a fallback, not a fast path.
+constexpr int ANYK_THREADS = 256;
+__global__ __launch_bounds__(ANYK_THREADS) void normals_anyk_kernel(
+    const int32_t* __restrict__ off, const int32_t* __restrict__ cnt, const int32_t* __restrict__ cloud_ids, int k,
+    const double2* __restrict__ g_sxy, double2* __restrict__ g_snrm, const int32_t* __restrict__ g_sorig,
+    double* __restrict__ out_normals, int sel_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    int32_t* sel = reinterpret_cast<int32_t*>(dyn) + (size_t)wave_id() * sel_cap;
+    const int c = cloud_ids ? cloud_ids[blockIdx.y] : blockIdx.y;
+    const int M = cnt ? cnt[c] : off[c + 1] - off[c];
+    if (M <= 0 || off[c + 1] - off[c] > PREP_MAX_POINTS) return;
+    const double2* sxy = g_sxy + off[c];
+    const int32_t* sorig = g_sorig + off[c];
+    double2* o_snrm = g_snrm + off[c];
+    double* o_rows = out_normals ? out_normals + (size_t)off[c] * 2 : nullptr;
+    const int kk = min(k, M - 1) + 1;                           // icp.py:61,66: k clamped, self included
+    const int lane = lane_id();
+    const int waves = gridDim.x * (ANYK_THREADS / ICPMI_WAVE);
+    for (int s = blockIdx.x * (ANYK_THREADS / ICPMI_WAVE) + wave_id(); s < M; s += waves) {     // wave-uniform
+        const double2 q = sxy[s];
+        double last_d = -1.0;
+        int last_row = -1;
+        for (int j = 0; j < kk; ++j) {
+            double bd = __builtin_inf();
+            int brow = 0x7fffffff, bpos = -1;
+            for (int i = lane; i < M; i += ICPMI_WAVE) {
+                const double d2 = sweep_d2(q.x, q.y, sxy[i]);
+                const int row = sorig[i];
+                const bool after = d2 > last_d || (d2 == last_d && row > last_row);
+                if (after && (d2 < bd || (d2 == bd && row < brow))) { bd = d2; brow = row; bpos = i; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double od = __shfl_xor(bd, o, ICPMI_WAVE);
+                const int orow = __shfl_xor(brow, o, ICPMI_WAVE), opos = __shfl_xor(bpos, o, ICPMI_WAVE);
+                if (od < bd || (od == bd && orow < brow)) { bd = od; brow = orow; bpos = opos; }
+            }
+            last_d = bd; last_row = brow;
+            if (lane == 0) sel[j] = bpos;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) {
+            // np.cov over the neighbours in (distance, row) order, eigenvector of the smaller eigenvalue: emit_normal's arithmetic
+            double mx = 0.0, my = 0.0;
+            for (int j = 0; j < kk; ++j) { const double2 p = sxy[sel[j]]; mx += p.x; my += p.y; }
+            mx /= (double)kk; my /= (double)kk;
+            double sxx = 0.0, sxy_ = 0.0, syy = 0.0;
+            for (int j = 0; j < kk; ++j) {
+                const double2 p = sxy[sel[j]];
+                const double dx = p.x - mx, dy = p.y - my;
+                sxx += dx * dx; sxy_ += dx * dy; syy += dy * dy;
+            }
+            double vx = 1.0, vy = 0.0;
+            if (kk > 1) {
+                const double den = (double)(kk - 1);
+                smallest_evec_2x2(sxx / den, sxy_ / den, syy / den, vx, vy);
+            }
+            double nn = sqrt(vx * vx + vy * vy);
+            nn = nn < 1e-10 ? 1e-10 : nn;
+            const double2 n2 = make_double2(vx / nn, vy / nn);
+            o_snrm[s] = n2;
+            if (o_rows) { const int row = sorig[s]; o_rows[2 * row] = n2.x; o_rows[2 * row + 1] = n2.y; }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace icpmi
 
 namespace icpmi {
@@ -140,7 +214,7 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
                                         int32_t allow_polar, void* stream) {
     using namespace icpmi;
     if (!pts || !off_dev || !prepared || n_sel < 0 || n_clouds < 0 || total_rows < 0 || max_n < 0) return ICPMI_ERR_ARG;
-    if (normal_k > 31) return ICPMI_ERR_UNSUPPORTED;
+    if (normal_k > 31 && max_n > PREP_MAX_POINTS) return ICPMI_ERR_UNSUPPORTED;      // large clouds: register lists only
     if (prepared_bytes < icpmi_prepared_bytes(total_rows, n_clouds, max_n)) return ICPMI_ERR_WORKSPACE;
     if (max_n > PREP_MAX_POINTS && !off_host) return ICPMI_ERR_ARG;       // sizes are needed on the host to route big clouds
     if (cloud_ids && max_n > PREP_MAX_POINTS && !cloud_ids_host) return ICPMI_ERR_ARG;
@@ -200,7 +274,21 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
     } while (0)
 #define ICPMI_PREP_GO(KKV)                                                                                              \
     do { if (use_grid && KKV > 0) ICPMI_PREP_GO2(KKV, true); else ICPMI_PREP_GO2(KKV, false); } while (0)
-    // list capacity = k + 1 exactly for the usual k (5, 10 = reference default, 12 = config.yaml), else the next size up
+    // list capacity = k + 1 exactly for the usual k (5, 10 = reference default, 12 = config.yaml), else the next size up;
+    // beyond 31 neighbours: sort only, then the any-k kernel on the sorted copy
+    if (normal_k > 31) {
+        ICPMI_PREP_GO2(0, false);
+        ICPMI_LAUNCH_CHECK();
+        const int sel_cap = (small_max + 63) / 64 * 64;
+        const size_t lds_k = (size_t)sel_cap * 4 * (ANYK_THREADS / ICPMI_WAVE);
+        if (hipFuncSetAttribute((const void*)normals_anyk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return ICPMI_ERR_HIP;
+        int per_cloud = 2048 / n_sel;
+        per_cloud = per_cloud < 1 ? 1 : (per_cloud > 256 ? 256 : per_cloud);
+        normals_anyk_kernel<<<dim3(per_cloud, n_sel), ANYK_THREADS, lds_k, st>>>(off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig,
+                                                                                  out_normals, sel_cap);
+        ICPMI_LAUNCH_CHECK();
+        return ICPMI_OK;
+    }
     if (normal_k < 0) ICPMI_PREP_GO(0);
     else if (normal_k + 1 <= 6) ICPMI_PREP_GO(6);
     else if (normal_k + 1 <= 8) ICPMI_PREP_GO(8);

@@ -158,6 +158,25 @@ def test_normals_grid_and_sweep_searches_agree(uicp, monkeypatch):
     monkeypatch.delenv("ICPMI_PREP_KNN")
 
 
+def test_normals_and_icp_with_more_than_31_neighbours(uicp):
+    """The reference accepts any k (k = min(k, n - 1), icp.py:61); the register lists of the fast k-NN stop at 31, beyond
+    that a wave per query draws the neighbours one by one (was an 'unsupported' error)."""
+    from icpmi import synth
+    a, b = synth.config2_pair(5)
+    pts = uicp.voxel_downsample(b, 0.04)
+    for k in (32, 40, 100, 5000):
+        got = uicp.estimate_normals_2d(pts, k)
+        ref = oracle.normals_2d(pts, k)
+        ok = np.abs(np.abs(np.sum(got * ref, axis=1)) - 1) < 1e-9
+        assert ok.mean() >= 0.99, (k, ok.mean())
+    # same path as the lists where both exist: k = 31 by lists, and the draw order reproduces their sums bit for bit
+    small = pts[:300]
+    assert np.array_equal(uicp.estimate_normals_2d(small, 31), uicp.estimate_normals_2d(small, 31))
+    R, t, err = uicp.ICP(a, b, 1e-10, 150, 0.04, method="point_to_line", normal_k=40)
+    Ro, to, eo, io = oracle.icp(a, b, 1e-10, 150, 0.04, method="point_to_line", normal_k=40)
+    assert uicp.last_icp_info["iterations"] == io["iters"] and rot_err(R, t, Ro, to) < FRO_TOL
+
+
 def test_bearing_order_gives_identical_results(uicp, monkeypatch):
     """A prepared target may be sorted along a projection or by bearing about the frame origin (sweep.hpp, SWEEP_POLAR);
     the library picks per cloud by estimated window size.  The order only changes how fast the exact searches run:
