@@ -162,6 +162,35 @@ __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
     const double packed_range = cells * (double)npad;                   // packed values are below this
     if (packed_range < 4.0e9) {
         uint32_t* pk = rows;                                             // sorted in the row array, unpacked in place
+        if (npad == 4 * (int)blockDim.x || npad == 2 * (int)blockDim.x) {
+            // the usual shape (a 2 048-beam scan on 512 or 1 024 threads): the network runs on registers (sort.hpp)
+            auto packed = [&](int i) {
+                return i < n ? (uint32_t)(vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel) << row_bits) | (uint32_t)i : 0xffffffffu;
+            };
+            auto unpack = [&](int i, uint32_t v) {
+                keys[i] = v == 0xffffffffu ? ~0ull : (uint64_t)(v >> row_bits);
+                rows[i] = v == 0xffffffffu ? 0xffffffffu : (v & ((1u << row_bits) - 1u));
+            };
+            uint32_t* scratch = reinterpret_cast<uint32_t*>(keys);          // the key array is free until the unpacking
+            if (npad == 4 * (int)blockDim.x) {
+                uint32_t v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = packed((int)threadIdx.x * 4 + e);
+                bitonic_sort_regs<uint32_t, 4>(v, scratch);
+                __syncthreads();                                            // scratch reads of the last LDS stage are done
+#pragma unroll
+                for (int e = 0; e < 4; ++e) unpack((int)threadIdx.x * 4 + e, v[e]);
+            } else {
+                uint32_t v[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) v[e] = packed((int)threadIdx.x * 2 + e);
+                bitonic_sort_regs<uint32_t, 2>(v, scratch);
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < 2; ++e) unpack((int)threadIdx.x * 2 + e, v[e]);
+            }
+            __syncthreads();
+        } else {
         for (int i = threadIdx.x; i < npad; i += blockDim.x)
             pk[i] = i < n ? (uint32_t)(vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel) << row_bits) | (uint32_t)i : 0xffffffffu;
         __syncthreads();
@@ -172,6 +201,7 @@ __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
             rows[i] = v == 0xffffffffu ? 0xffffffffu : (v & ((1u << row_bits) - 1u));
         }
         __syncthreads();
+        }
     } else if (packed_range < 9.0e18) {
         for (int i = threadIdx.x; i < npad; i += blockDim.x)
             keys[i] = i < n ? (vox_key(P + (size_t)i * DIM, DIM, mn, ext, voxel) << row_bits) | (uint64_t)i : ~0ull;
