@@ -123,7 +123,11 @@ __device__ __forceinline__ void combine_totals(const double* scratch, int n_wave
 }
 
 // control block published by wave 0: r (4), t (2), stop flag, mean_p (2), mean_q (2)
-constexpr int CTRL_R = 0, CTRL_T = 4, CTRL_STOP = 6, CTRL_MP = 8, CTRL_MQ = 10, CTRL_DOUBLES = 12;
+constexpr int CTRL_R = 0, CTRL_T = 4, CTRL_STOP = 6, CTRL_MP = 8, CTRL_MQ = 10;
+// state carried from iteration to iteration by thread 0 alone (accumulated transform, errors, outcome): kept in LDS,
+// not in registers — live across the search it would cost every thread of the workgroup 20 registers
+constexpr int CTRL_RT = 12, CTRL_TT = 16, CTRL_ERR = 18, CTRL_PREV = 19, CTRL_DELTA = 20, CTRL_ITERS = 21, CTRL_STATUS = 22,
+              CTRL_DOUBLES = 24;
 
 #ifndef ICP2_PLAIN_ITERS
 #define ICP2_PLAIN_ITERS 2      // iterations that search the plain nearest neighbour before budgets are kept
@@ -135,6 +139,45 @@ constexpr int CTRL_R = 0, CTRL_T = 4, CTRL_STOP = 6, CTRL_MP = 8, CTRL_MQ = 10, 
 // TGT_LDS: the prepared target is staged in LDS (<= 4096 points); otherwise it is read in place, through L2
 // FILT (with TGT_LDS): the LDS copy carries a float32 image per point instead of the row map (48 B instead of
 // 36 B per point) and the searches judge every candidate on it first (sweep.hpp, "single-precision filter")
+// A value every lane of the wave holds alike, moved to scalar registers (it stays live across the whole search).
+__device__ __forceinline__ double wave_uniform(double v) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ float wave_uniform(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// Finish step it-1 (icp.py:215-220: mean squared error of the step, its change, convergence) and test the inlier
+// count of step it (icp.py:186).  Every lane of the lead wave evaluates the same values; the writer lane stores.
+__device__ __forceinline__ bool finish_step(double* ctrl, int it, double err_sum, double inliers, int N, bool has_corr,
+                                            int need, double error_threshold, bool writer) {
+    bool stop = false;
+    if (it > 0) {
+        const double err = err_sum / (double)N, delta = fabs(ctrl[CTRL_PREV] - err);
+        stop = delta < error_threshold;
+        if (writer) {
+            ctrl[CTRL_ERR] = err; ctrl[CTRL_DELTA] = delta; ctrl[CTRL_PREV] = err; ctrl[CTRL_ITERS] = (double)it;
+            if (stop) ctrl[CTRL_STATUS] = (double)ICPMI_ST_CONVERGED;
+        }
+    }
+    if (!stop && has_corr && inliers < (double)need) {
+        stop = true;
+        if (writer) { ctrl[CTRL_STATUS] = (double)ICPMI_ST_FEW_INLIERS; ctrl[CTRL_ITERS] = (double)it; }
+    }
+    return stop;
+}
+
+// R_total = R R_total, t_total = t_total R^T + t: icp.py:210-211
+__device__ __forceinline__ void accumulate_step(double* ctrl, const double (&r)[4], const double (&t)[2]) {
+    const double rt0 = ctrl[CTRL_RT], rt1 = ctrl[CTRL_RT + 1], rt2 = ctrl[CTRL_RT + 2], rt3 = ctrl[CTRL_RT + 3];
+    const double tt0 = ctrl[CTRL_TT], tt1 = ctrl[CTRL_TT + 1];
+    ctrl[CTRL_RT] = r[0] * rt0 + r[1] * rt2; ctrl[CTRL_RT + 1] = r[0] * rt1 + r[1] * rt3;
+    ctrl[CTRL_RT + 2] = r[2] * rt0 + r[3] * rt2; ctrl[CTRL_RT + 3] = r[2] * rt1 + r[3] * rt3;
+    ctrl[CTRL_TT] = (tt0 * r[0] + tt1 * r[1]) + t[0]; ctrl[CTRL_TT + 1] = (tt0 * r[2] + tt1 * r[3]) + t[1];
+}
+
 template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT>
 __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   // 4 waves/SIMD: 2 x 512 or 1 x 1024 per CU
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
@@ -169,18 +212,17 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
     __shared__ int rt_bits;                                      // max(|x - ox|, |y - oy|) over the target, float32 bits
     if (FILT && tid == 0) rt_bits = 0;
 
-    double rt[4] = {1.0, 0.0, 0.0, 1.0}, tt[2] = {0.0, 0.0};
-    if (a.has_init) {                                       // icp.py:153-156
-        const double* in = a.init + (size_t)b * 6;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rt[i] = in[i];
-        tt[0] = in[4]; tt[1] = in[5];
+    if (tid == 0) {
+        const double* in = a.init + (size_t)b * 6;          // icp.py:153-156
+        ctrl[CTRL_RT] = a.has_init ? in[0] : 1.0; ctrl[CTRL_RT + 1] = a.has_init ? in[1] : 0.0;
+        ctrl[CTRL_RT + 2] = a.has_init ? in[2] : 0.0; ctrl[CTRL_RT + 3] = a.has_init ? in[3] : 1.0;
+        ctrl[CTRL_TT] = a.has_init ? in[4] : 0.0; ctrl[CTRL_TT + 1] = a.has_init ? in[5] : 0.0;
+        ctrl[CTRL_ERR] = __builtin_inf(); ctrl[CTRL_PREV] = __builtin_inf(); ctrl[CTRL_DELTA] = __builtin_inf();
+        ctrl[CTRL_ITERS] = 0.0; ctrl[CTRL_STATUS] = (double)ICPMI_ST_MAXITER;
     }
-    double err = __builtin_inf(), prev = __builtin_inf(), delta = __builtin_inf();
-    int iters = 0, status = ICPMI_ST_MAXITER;
 
     if (N <= 0 || M <= 0 || dir < 0 || (TGT_LDS && M > a.lds_points) || N > THREADS * ICP2_SMAX || (!FILT && dir >= SWEEP_POLAR)) {
-        status = ICPMI_ST_EMPTY;                            // the launcher only sends pairs that fit
+        if (tid == 0) ctrl[CTRL_STATUS] = (double)ICPMI_ST_EMPTY;   // the launcher only sends pairs that fit
     } else {
         const bool use_p2l = a.method == ICPMI_POINT_TO_LINE;
         // stage the prepared target: coalesced 16-B reads
@@ -200,7 +242,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
             // order — to the frame origin the bearings are taken about
             if (dir != SWEEP_POLAR) {
                 const double2 o = gx[M >> 1];
-                filt.ox = o.x; filt.oy = o.y; filt.uo = proj(dir, o.x, o.y);
+                filt.ox = wave_uniform(o.x); filt.oy = wave_uniform(o.y); filt.uo = wave_uniform(proj(dir, o.x, o.y));
             }
             float rmax = 0.0f;
             for (int i = tid; i < M; i += THREADS) {
@@ -245,23 +287,24 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
             if (n < N) {
                 const double x = src[2 * n], y = src[2 * n + 1];
                 if (a.has_init) {                           // source @ R_init.T + t_init
+                    const double* in = a.init + (size_t)b * 6;
                     double sx = 0.0, sy = 0.0;
-                    sx += x * rt[0]; sx += y * rt[1]; sx += tt[0];
-                    sy += x * rt[2]; sy += y * rt[3]; sy += tt[1];
+                    sx += x * in[0]; sx += y * in[1]; sx += in[4];
+                    sy += x * in[2]; sy += y * in[3]; sy += in[5];
                     px[s] = sx; py[s] = sy;
                 } else { px[s] = x; py[s] = y; }
             }
         }
         const bool has_corr = a.max_corr_dist >= 0.0;
-        const double max_corr_sq = a.max_corr_dist * a.max_corr_dist;   // icp.py:169
+        const double max_corr_sq = wave_uniform(a.max_corr_dist * a.max_corr_dist);   // icp.py:169
         const int need = max(3, N / 10);                                 // icp.py:186
         __syncthreads();
         // largest |projection| of the target (the copy is sorted along it): rounding slack of the diagonal axes
         const double2 c_lo = sxy[0], c_hi = sxy[M - 1];
-        const double uabs = fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y)));
+        const double uabs = wave_uniform(fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y))));
         if constexpr (FILT) {
-            filt.rt = __int_as_float(rt_bits) * 1.000001f;
-            filt.ut = fmaxf(fabsf(lds_sq[0].z), fabsf(lds_sq[M - 1].z)) * 1.000001f;     // the images are sorted like the keys
+            filt.rt = wave_uniform(__int_as_float(rt_bits) * 1.000001f);
+            filt.ut = wave_uniform(fmaxf(fabsf(lds_sq[0].z), fabsf(lds_sq[M - 1].z)) * 1.000001f);     // the images are sorted like the keys
         }
 
         double e_part = 0.0;          // this thread's share of the squared error of the step just applied
@@ -373,15 +416,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                 DIAG_SET(c2);
                 if (lead) {
                     combine_totals<11>(redA, NWAVES, acc);
-                    bool stop = false;
-                    if (it > 0) {                                                  // finish step it-1: icp.py:215-220
-                        err = acc[10] / (double)N;
-                        iters = it;
-                        delta = fabs(prev - err);
-                        if (delta < a.error_threshold) { status = ICPMI_ST_CONVERGED; stop = true; }
-                        prev = err;
-                    }
-                    if (!stop && has_corr && acc[9] < (double)need) { status = ICPMI_ST_FEW_INLIERS; iters = it; stop = true; }
+                    const bool stop = finish_step(ctrl, it, acc[10], acc[9], N, has_corr, need, a.error_threshold, tid == 0);
                     if (!stop) {
                         double A[3][3] = {{acc[0], acc[1], acc[2]}, {acc[1], acc[3], acc[4]}, {acc[2], acc[4], acc[5]}};
                         double rhs[3] = {acc[6], acc[7], acc[8]}, x[3];
@@ -394,11 +429,8 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                             r[0] = 1.0; r[1] = 0.0; r[2] = 0.0; r[3] = 1.0; t[0] = 0.0; t[1] = 0.0;
                         }
                         // accumulate totals, icp.py:210-211
-                        const double n0 = r[0] * rt[0] + r[1] * rt[2], n1 = r[0] * rt[1] + r[1] * rt[3];
-                        const double n2 = r[2] * rt[0] + r[3] * rt[2], n3 = r[2] * rt[1] + r[3] * rt[3];
-                        const double u0 = (tt[0] * r[0] + tt[1] * r[1]) + t[0], u1 = (tt[0] * r[2] + tt[1] * r[3]) + t[1];
-                        rt[0] = n0; rt[1] = n1; rt[2] = n2; rt[3] = n3; tt[0] = u0; tt[1] = u1;
                         if (tid == 0) {
+                            accumulate_step(ctrl, r, t);
                             ctrl[CTRL_R] = r[0]; ctrl[CTRL_R + 1] = r[1]; ctrl[CTRL_R + 2] = r[2]; ctrl[CTRL_R + 3] = r[3];
                             ctrl[CTRL_T] = t[0]; ctrl[CTRL_T + 1] = t[1];
                         }
@@ -430,15 +462,7 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                 DIAG_SET(c2);
                 if (lead) {
                     combine_totals<6>(redA, NWAVES, m);
-                    bool stop = false;
-                    if (it > 0) {
-                        err = m[5] / (double)N;
-                        iters = it;
-                        delta = fabs(prev - err);
-                        if (delta < a.error_threshold) { status = ICPMI_ST_CONVERGED; stop = true; }
-                        prev = err;
-                    }
-                    if (!stop && has_corr && m[4] < (double)need) { status = ICPMI_ST_FEW_INLIERS; iters = it; stop = true; }
+                    const bool stop = finish_step(ctrl, it, m[5], m[4], N, has_corr, need, a.error_threshold, tid == 0);
                     if (tid == 0) {
                         ctrl[CTRL_STOP] = stop ? 1.0 : 0.0;
                         ctrl[CTRL_MP] = m[0] / m[4]; ctrl[CTRL_MP + 1] = m[1] / m[4];
@@ -467,11 +491,8 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
                     s0 += r[0] * mpx; s0 += r[1] * mpy;
                     s1 += r[2] * mpx; s1 += r[3] * mpy;
                     t[0] = mqx - s0; t[1] = mqy - s1;                              // icp.py:207
-                    const double n0 = r[0] * rt[0] + r[1] * rt[2], n1 = r[0] * rt[1] + r[1] * rt[3];
-                    const double n2 = r[2] * rt[0] + r[3] * rt[2], n3 = r[2] * rt[1] + r[3] * rt[3];
-                    const double u0 = (tt[0] * r[0] + tt[1] * r[1]) + t[0], u1 = (tt[0] * r[2] + tt[1] * r[3]) + t[1];
-                    rt[0] = n0; rt[1] = n1; rt[2] = n2; rt[3] = n3; tt[0] = u0; tt[1] = u1;
                     if (tid == 0) {
+                        accumulate_step(ctrl, r, t);
                         ctrl[CTRL_R] = r[0]; ctrl[CTRL_R + 1] = r[1]; ctrl[CTRL_R + 2] = r[2]; ctrl[CTRL_R + 3] = r[3];
                         ctrl[CTRL_T] = t[0]; ctrl[CTRL_T + 1] = t[1];
                     }
@@ -512,10 +533,12 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
             __syncthreads();
             if (lead) {
                 combine_totals<1>(redA, NWAVES, e);
-                err = e[0] / (double)N;
-                iters = a.max_iterations;
-                delta = fabs(prev - err);
-                if (delta < a.error_threshold) status = ICPMI_ST_CONVERGED;
+                if (tid == 0) {
+                    const double err = e[0] / (double)N, delta = fabs(ctrl[CTRL_PREV] - err);
+                    ctrl[CTRL_ERR] = err; ctrl[CTRL_DELTA] = delta;
+                    ctrl[CTRL_ITERS] = (double)a.max_iterations;
+                    if (delta < a.error_threshold) ctrl[CTRL_STATUS] = (double)ICPMI_ST_CONVERGED;
+                }
             }
         }
     }
@@ -524,12 +547,12 @@ __global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   
 #pragma unroll
         for (int i = 0; i < ICPMI_RES_DOUBLES; ++i) res[i] = 0.0;
 #endif
-        res[0] = rt[0]; res[1] = rt[1]; res[2] = rt[2]; res[3] = rt[3];
-        res[ICPMI_RES_T] = tt[0]; res[ICPMI_RES_T + 1] = tt[1];
-        res[ICPMI_RES_ERR] = err;
-        res[ICPMI_RES_DELTA] = delta;
-        res[ICPMI_RES_ITERS] = (double)iters;
-        res[ICPMI_RES_STATUS] = (double)status;
+        res[0] = ctrl[CTRL_RT]; res[1] = ctrl[CTRL_RT + 1]; res[2] = ctrl[CTRL_RT + 2]; res[3] = ctrl[CTRL_RT + 3];
+        res[ICPMI_RES_T] = ctrl[CTRL_TT]; res[ICPMI_RES_T + 1] = ctrl[CTRL_TT + 1];
+        res[ICPMI_RES_ERR] = ctrl[CTRL_ERR];
+        res[ICPMI_RES_DELTA] = ctrl[CTRL_DELTA];
+        res[ICPMI_RES_ITERS] = ctrl[CTRL_ITERS];
+        res[ICPMI_RES_STATUS] = ctrl[CTRL_STATUS];
     }
 }
 
