@@ -243,7 +243,7 @@ __device__ __forceinline__ float apply_counts(float v0, uint32_t H, uint32_t M, 
 // the finalise pass replays the grids in scan order, so the result is the sequential one bit for bit); the
 // launches of a replay drop from one per scan to one per group.
 #ifndef ICPMI_RC_GROUP
-#define ICPMI_RC_GROUP 16
+#define ICPMI_RC_GROUP 32
 #endif
 constexpr int RC_GROUP_MAX = ICPMI_RC_GROUP;
 struct ScanGroup {
@@ -356,6 +356,232 @@ __global__ __launch_bounds__(RC_THREADS) void ray_step_kernel(
     else ray_finalize_body(g, f, blockIdx.x - n_count, gridDim.x - n_count);
 }
 
+// ── K6 by tiles: counters of a 64 x 64 tile in LDS ────────────────────────────────────────────────────────────────
+// The counting pass above is bound by the rate of scattered atomic line requests at L2 (~27 G/s on an MI355X
+// whatever the scope or the size of the region, tools/ubench/atomic_scope.hip; ~413 G/s when the 64 lanes of an
+// instruction fall on consecutive words), about one request per distinct (64-beam wave, cell).  Here a workgroup
+// owns one tile of one scan's counter grid and a quarter of the scan's beams: it cuts every beam to the tile
+// (exact step range from the closed form, after a bounding-box and a side-of-line rejection), walks the part
+// inside into LDS counters (LDS atomics: conflicts cost cycles, not requests), and adds the tile's non-zero
+// counters to the scan's grid row by row — consecutive words, one or two line requests per 64 cells.  Integer
+// counts, so the grids (and everything after them) are the same bit for bit.
+//   ray_scan_boxes_kernel  one workgroup per scan of the group: cell box of what its beams can touch (cut to the
+//                          window), so that the workgroups of the other tiles leave at once;
+//   ray_tile_body          one workgroup per (scan, tile, beam chunk).
+constexpr int RT_TILE = 64, RT_THREADS = 256;
+constexpr int RT_FAR = 4, RT_CHUNKS = 16;           // workgroups per (scan, tile): 4, and 16 for the 3 x 3 tiles around the origin
+__host__ __device__ constexpr int rt_blocks_per_scan(int n_tiles) { return n_tiles * RT_FAR + 9 * (RT_CHUNKS - RT_FAR); }
+constexpr int RT_STEPS = 16, RT_BLOCKS = RT_TILE / RT_STEPS;   // a thread walks blocks of 16 steps
+
+struct ScanBox { int x0, y0, x1, y1; };           // inclusive; x1 < x0: nothing to touch
+
+// beams of a scan are cut into RT_CHUNKS parts of rt_part(nb) consecutive beams (whole waves)
+__host__ __device__ constexpr int rt_part(int nb) { return ((nb + RT_CHUNKS - 1) / RT_CHUNKS + ICPMI_WAVE - 1) & ~(ICPMI_WAVE - 1); }
+
+constexpr int RT_BOXES = 1 + RT_CHUNKS;           // per scan: the box of the scan, then one per part
+
+// boxes[s * RT_BOXES]: what the beams of scan s can touch, cut to the window; boxes[s * RT_BOXES + 1 + p]: the same
+// for part p alone — a lidar reports its beams in angular order, so a part is a wedge and most tiles lie outside
+// its box (any order is correct; it only decides how many beams a tile has to look at).  One workgroup per scan
+// (one per part measured slower: 16 times the workgroups for the dispatcher).
+__device__ __forceinline__ void ray_scan_boxes_body(const GridDesc& g, const double* __restrict__ origins,
+                                                    const double* __restrict__ hits, const ScanGroup& grp,
+                                                    ScanBox* __restrict__ boxes, int s) {
+    __shared__ uint32_t bb[RT_BOXES][4];
+    const int tid = threadIdx.x;
+    const int nb = grp.nb[s], part = rt_part(nb);
+    const double* h = hits + 2 * (size_t)grp.hit_row[s];
+    const double* origin = origins + 2 * (size_t)grp.origin_row[s];
+    if (tid < RT_BOXES * 4) (&bb[0][0])[tid] = 0u;
+    int ox = 0, oy = 0;
+    const bool ok = world_to_cell(origin[0], g.min_x, g.res, ox) && world_to_cell(origin[1], g.min_y, g.res, oy);
+    __syncthreads();
+    for (int base = 0; ok && base < nb; base += RT_THREADS) {           // a wave's 64 beams belong to one part
+        const int i = base + tid;
+        uint32_t a = 0, b = 0, c = 0, d = 0;
+        int hx = 0, hy = 0;
+        if (i < nb && world_to_cell(h[2 * (size_t)i], g.min_x, g.res, hx) && world_to_cell(h[2 * (size_t)i + 1], g.min_y, g.res, hy)) {
+            const int bx0 = max(g.wx0, min(ox, hx)), bx1 = min(g.wx1 - 1, max(ox, hx));
+            const int by0 = max(g.wy0, min(oy, hy)), by1 = min(g.wy1 - 1, max(oy, hy));
+            if (bx0 <= bx1 && by0 <= by1) { a = (uint32_t)(g.nx - bx0); b = (uint32_t)(g.ny - by0); c = (uint32_t)(bx1 + 1); d = (uint32_t)(by1 + 1); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            a = max(a, (uint32_t)__shfl_xor((int)a, o, ICPMI_WAVE));
+            b = max(b, (uint32_t)__shfl_xor((int)b, o, ICPMI_WAVE));
+            c = max(c, (uint32_t)__shfl_xor((int)c, o, ICPMI_WAVE));
+            d = max(d, (uint32_t)__shfl_xor((int)d, o, ICPMI_WAVE));
+        }
+        if (lane_id() == 0 && a) {
+            const int p = 1 + i / part;
+            atomicMax(&bb[0][0], a); atomicMax(&bb[0][1], b); atomicMax(&bb[0][2], c); atomicMax(&bb[0][3], d);
+            atomicMax(&bb[p][0], a); atomicMax(&bb[p][1], b); atomicMax(&bb[p][2], c); atomicMax(&bb[p][3], d);
+        }
+    }
+    __syncthreads();
+    if (tid < RT_BOXES) {
+        ScanBox r{0, 0, -1, -1};
+        if (bb[tid][0]) r = ScanBox{g.nx - (int)bb[tid][0], g.ny - (int)bb[tid][1], (int)bb[tid][2] - 1, (int)bb[tid][3] - 1};
+        boxes[(size_t)s * RT_BOXES + tid] = r;
+    }
+}
+
+__global__ __launch_bounds__(RT_THREADS) void ray_scan_boxes_kernel(GridDesc g, const double* __restrict__ origins,
+                                                                   const double* __restrict__ hits, ScanGroup grp,
+                                                                   ScanBox* __restrict__ boxes) {
+    ray_scan_boxes_body(g, origins, hits, grp, boxes, blockIdx.x);
+}
+
+struct TileArgs {
+    const ScanBox* boxes;      // boxes of the scans of the group
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ void ray_tile_body(const GridDesc& g, const double* __restrict__ origins,
+                                              const double* __restrict__ hits, const ScanGroup& grp,
+                                              uint32_t* __restrict__ counts, size_t grid_stride, BBox* bbox,
+                                              const TileArgs& ta, int block) {
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[RT_TILE * RT_TILE];
+    __shared__ int4 seg[RT_THREADS];                    // beams of this pass that cross the tile: hit cell, step range
+    __shared__ uint16_t items[RT_THREADS * RT_BLOCKS];  // (beam << 2 | block of RT_STEPS steps)
+    __shared__ int n_items;
+    const int n_tiles = ta.tiles_x * ta.tiles_y, per_scan = rt_blocks_per_scan(n_tiles);
+    const int s = block / per_scan, rem = block - s * per_scan;
+    const int tid = threadIdx.x;
+    const double* origin = origins + 2 * (size_t)grp.origin_row[s];
+    int ox = 0, oy = 0;
+    const bool ok = world_to_cell(origin[0], g.min_x, g.res, ox) && world_to_cell(origin[1], g.min_y, g.res, oy);
+    // Every tile has RT_FAR workgroups, each with a quarter of the beams.  The 3 x 3 tiles around the origin see every
+    // beam at full length: their beams are cut into RT_CHUNKS parts, and the extra workgroups come after the regular ones.
+    const int otx = (ox - g.wx0) >> 6, oty = (oy - g.wy0) >> 6;            // arithmetic shift: floor, also left of the window
+    int tcx, tcy, chunk;
+    if (rem < n_tiles * RT_FAR) {
+        const int tile = rem / RT_FAR;
+        chunk = rem - tile * RT_FAR;
+        tcx = tile % ta.tiles_x; tcy = tile / ta.tiles_x;
+    } else {
+        const int e = rem - n_tiles * RT_FAR, nt = e / (RT_CHUNKS - RT_FAR);
+        chunk = RT_FAR + e - nt * (RT_CHUNKS - RT_FAR);
+        tcx = otx + nt % 3 - 1; tcy = oty + nt / 3 - 1;
+        if (tcx < 0 || tcx >= ta.tiles_x || tcy < 0 || tcy >= ta.tiles_y) return;
+    }
+    const bool near = abs(tcx - otx) <= 1 && abs(tcy - oty) <= 1;
+    const bool first = rem == 0;
+    const int x0 = g.wx0 + tcx * RT_TILE, y0 = g.wy0 + tcy * RT_TILE;
+    const int x1 = min(x0 + RT_TILE, g.wx1), y1 = min(y0 + RT_TILE, g.wy1);
+    if (ta.boxes) {
+        const ScanBox sb = ta.boxes[(size_t)s * RT_BOXES];
+        if (first && tid == 0 && sb.x1 >= sb.x0) {                       // the group's box for the finalise pass
+            atomicMax(&bbox->inv_x0, (uint32_t)(g.nx - sb.x0)); atomicMax(&bbox->inv_y0, (uint32_t)(g.ny - sb.y0));
+            atomicMax(&bbox->x1p, (uint32_t)(sb.x1 + 1)); atomicMax(&bbox->y1p, (uint32_t)(sb.y1 + 1));
+        }
+        if (sb.x1 < x0 || sb.x0 >= x1 || sb.y1 < y0 || sb.y0 >= y1) return;              // uniform: the scan does not reach this tile
+    } else if (first && tid == 0) {                                     // a single scan: the caller's box is the scan's
+        atomicMax(&bbox->inv_x0, (uint32_t)(g.nx - g.wx0)); atomicMax(&bbox->inv_y0, (uint32_t)(g.ny - g.wy0));
+        atomicMax(&bbox->x1p, (uint32_t)g.wx1); atomicMax(&bbox->y1p, (uint32_t)g.wy1);
+    }
+    const double* h = hits + 2 * (size_t)grp.hit_row[s];
+    // a near workgroup takes one part of the beams, a far one four
+    const int nb = grp.nb[s], part = rt_part(nb);
+    const int p0 = near ? chunk : chunk * (RT_CHUNKS / RT_FAR), p1 = near ? chunk + 1 : (chunk + 1) * (RT_CHUNKS / RT_FAR);
+    if ((!near && chunk >= RT_FAR) || p0 * part >= nb || !ok) return;
+    uint4* cnt4 = reinterpret_cast<uint4*>(cnt);
+    bool dirty = false;                                                  // uniform: the counters are zeroed by the first pass that needs them
+    for (int pt = p0; pt < p1 && pt * part < nb; ++pt) {
+      if (ta.boxes) {                                                    // the part's wedge misses the tile: skip its beams unread
+          const ScanBox pb = ta.boxes[(size_t)s * RT_BOXES + 1 + pt];
+          if (pb.x1 < x0 || pb.x0 >= x1 || pb.y1 < y0 || pb.y0 >= y1) continue;
+      }
+      const int b1 = min(nb, (pt + 1) * part);
+      for (int base = pt * part; base < b1; base += RT_THREADS) {        // uniform trip counts
+        if (tid == 0) n_items = 0;
+        const int i = base + tid;
+        int hx = 0, hy = 0, klo = 0, khi = 0;
+        bool hit_in = false;
+        if (i < b1 && world_to_cell(h[2 * (size_t)i], g.min_x, g.res, hx) && world_to_cell(h[2 * (size_t)i + 1], g.min_y, g.res, hy)) {
+            hit_in = hx >= x0 && hx < x1 && hy >= y0 && hy < y1;
+            // Bresenham stays inside the rectangle of its end points ...
+            bool cross = !(max(ox, hx) < x0 || min(ox, hx) >= x1 || max(oy, hy) < y0 || min(oy, hy) >= y1);
+            if (cross) {
+                // ... and within one cell of the straight line: a tile (grown by a cell) whose corners all lie
+                // strictly on one side of the line cannot be touched
+                const long long dx = hx - ox, dy = hy - oy;
+                const long long cxa = x0 - 1 - ox, cxb = x1 - ox, cya = y0 - 1 - oy, cyb = y1 - oy;
+                const long long c0 = dx * cya - dy * cxa, c1 = dx * cya - dy * cxb, c2 = dx * cyb - dy * cxa, c3 = dx * cyb - dy * cxb;
+                cross = !((c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0) || (c0 < 0 && c1 < 0 && c2 < 0 && c3 < 0));
+            }
+            if (cross) {
+                Ray ray;
+                ray.init(ox, oy, hx, hy);
+                if (ray.xmajor) { ray.clip_major(x0, x1, klo, khi); ray.clip_minor(y0, y1, klo, khi); }
+                else { ray.clip_major(y0, y1, klo, khi); ray.clip_minor(x0, x1, klo, khi); }
+            }
+        }
+        if (!__syncthreads_or(hit_in || khi > klo)) continue;            // nothing of this pass touches the tile
+        if (!dirty) {
+            for (int c = tid; c < RT_TILE * RT_TILE / 4; c += RT_THREADS) cnt4[c] = make_uint4(0u, 0u, 0u, 0u);
+            dirty = true;
+            __syncthreads();
+        }
+        if (hit_in) atomicAdd(&cnt[(hy - y0) * RT_TILE + (hx - x0)], 0x10000u);     // mapping.py:124-129
+        if (khi > klo) {                                                 // at most RT_TILE steps: RT_BLOCKS blocks
+            const int nblk = (khi - klo + RT_STEPS - 1) / RT_STEPS;
+            const int slot = atomicAdd(&n_items, nblk);
+            seg[tid] = make_int4(hx, hy, klo, khi);
+            for (int b = 0; b < nblk; ++b) items[slot + b] = (uint16_t)(tid << 2 | b);
+        }
+        __syncthreads();
+        const int total = n_items;
+        for (int it = tid; it < total; it += RT_THREADS) {               // free cells, mapping.py:135-139
+            const int e = items[it];
+            const int4 sg = seg[e >> 2];
+            Ray ray;
+            ray.init(ox, oy, sg.x, sg.y);
+            const int k0 = sg.z + (e & 3) * RT_STEPS, k1 = min(sg.w, k0 + RT_STEPS);
+            ray.seek(k0);
+            for (int k = k0; k < k1; ++k) {
+                int x, y;
+                ray.cell(k, x, y);
+                atomicAdd(&cnt[(y - y0) * RT_TILE + (x - x0)], 1u);
+                ray.step();
+            }
+        }
+        __syncthreads();
+      }
+    }
+    if (!dirty) return;
+    uint32_t* plane = counts + (size_t)s * grid_stride;
+    for (int c = tid; c < RT_TILE * RT_TILE / 4; c += RT_THREADS) {      // four cells of a row per lane: a wave covers four rows
+        const uint4 v = cnt4[c];
+        if (!(v.x | v.y | v.z | v.w)) continue;
+        uint32_t* row = &plane[counter_index(g, x0 + ((c * 4) & (RT_TILE - 1)), y0 + ((c * 4) >> 6))];   // only cells inside the tile's cut were counted
+        if (v.x) atomicAdd(row, v.x);
+        if (v.y) atomicAdd(row + 1, v.y);
+        if (v.z) atomicAdd(row + 2, v.z);
+        if (v.w) atomicAdd(row + 3, v.w);
+    }
+}
+
+// One launch of a replay on the tile path: the first n_count workgroups count group k, the next n_fin finalise group
+// k-1 from the other set of counter grids (disjoint memory), the last ones find the scan boxes of group k+1.
+__global__ __launch_bounds__(RT_THREADS) void ray_tile_step_kernel(GridDesc g, const double* __restrict__ origins,
+                                                                  const double* __restrict__ hits, ScanGroup grp,
+                                                                  uint32_t* __restrict__ counts, size_t grid_stride, BBox* bbox, TileArgs ta,
+                                                                  int n_items, int n_count, int n_fin, FinArgs f, ScanGroup nxt,
+                                                                  ScanBox* nxt_boxes) {
+    // the boxes of the next group first: few workgroups with a long chain of dependent loads, they must not start last
+    if ((int)blockIdx.x < nxt.n) { ray_scan_boxes_body(g, origins, hits, nxt, nxt_boxes, blockIdx.x); return; }
+    const int b = blockIdx.x - nxt.n;
+    if (b < n_count) {
+        // n_count workgroups share the n_items (scan, tile, chunk) items: launching one workgroup per item is bound by
+        // the dispatch rate (~190 workgroups/us with 23 KB of LDS each), not by the work
+        for (int w = b; w < n_items; w += n_count) {
+            ray_tile_body(g, origins, hits, grp, counts, grid_stride, bbox, ta, w);
+            __syncthreads();                    // the counters are zeroed again by the next item
+        }
+    } else ray_finalize_body(g, f, b - n_count, n_fin);
+}
+
 __global__ void world_to_grid_kernel(const double* __restrict__ w, long long n, double mn, double res, long long* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (long long)floor((w[i] - mn) / res);
@@ -387,9 +613,10 @@ __global__ void bresenham_cells_kernel(const int32_t* __restrict__ segs, const l
 // (group parity) of up to RC_GROUP_MAX scans fit as long as the box is at most 1/8 of the grid — the usual case: a
 // lidar's reach against a map with tens of metres of margin; with larger boxes the groups shrink (two scans per
 // group for a box as large as the grid).
+// + the cell boxes of the scans of a group, two sets (tile path).
 extern "C" size_t icpmi_grid_workspace_bytes(int32_t ny, int32_t nx) {
     if (ny <= 0 || nx <= 0) return 0;
-    return 4 * (size_t)ny * (size_t)nx * sizeof(uint32_t) + 256;
+    return 4 * (size_t)ny * (size_t)nx * sizeof(uint32_t) + 256 + 2 * (size_t)icpmi::RC_GROUP_MAX * icpmi::RT_BOXES * sizeof(icpmi::ScanBox);
 }
 
 extern "C" int icpmi_world_to_grid(const double* w, int64_t n, double min_w, double resolution, int64_t* out, void* stream) {
@@ -462,6 +689,20 @@ extern "C" int icpmi_grid_update_scans_box(float* log_odds, void* counts_ws, int
     FinArgs fin{};
     fin.log_odds = log_odds; fin.l_hit = l_hit; fin.l_miss = l_miss; fin.lo32 = (float)lo; fin.hi32 = (float)hi;
     fin.grid_stride = cells; fin.n_grids = 1;
+    // The tile path needs the caller's box (the tiles of the window are enumerated; a scan's own box, found on the
+    // device, sends the other tiles home at once).  Without a box (a direct caller of the plain entry points, or
+    // non-finite coordinates) the window is the whole grid and the per-beam atomic pass runs instead.
+    // ICPMI_RAYCAST=atomic forces the latter (experiments, and the parity tests of both passes).
+    // A single scan (the live update) also takes the atomic pass: two short launches, 21 us against 32.
+    const char* rc_env = getenv("ICPMI_RAYCAST");
+    int live_scans = 0;
+    for (int t = 0; t < n_scans; ++t) live_scans += hit_off_host[t + 1] > hit_off_host[t] ? 1 : 0;
+    const bool tiles_ok = box_host && !empty_window && !(rc_env && rc_env[0] == 'a') && hits && (live_scans > 1 || (rc_env && rc_env[0] == 't'));
+    TileArgs ta{};
+    ScanBox* box_sets = (ScanBox*)((unsigned char*)counts_ws + capacity * sizeof(uint32_t) + 256);
+    ta.tiles_x = (wx1 - wx0 + RT_TILE - 1) / RT_TILE; ta.tiles_y = (wy1 - wy0 + RT_TILE - 1) / RT_TILE;
+    const char* wg_env = getenv("ICPMI_RT_WGS");
+    const int rt_wgs = wg_env && atoi(wg_env) > 0 ? atoi(wg_env) : 1536;      // resident workgroups of the tile pass (6 per CU)
     bool pending = false;            // a counted group whose finalisation rides on the next launch
     int64_t q = 0;                   // index of the next group (counter-grid set q&1, box slot q%3)
     int clip_all = full_clip;
@@ -469,6 +710,31 @@ extern "C" int icpmi_grid_update_scans_box(float* log_odds, void* counts_ws, int
         const long waves = (long)((nb + ICPMI_WAVE - 1) / ICPMI_WAVE) * RC_SLOTS;
         return (int)((waves * ICPMI_WAVE + RC_THREADS - 1) / RC_THREADS);
     };
+    // the group that starts at the first non-empty scan at or after `from`: 1 = built (end = one past its last scan),
+    // 0 = none (the replay ends, or a scan too wide for a group comes first), -1 = bad offsets
+    auto build_group = [&](int from, ScanGroup& gq, int& end) {
+        gq = ScanGroup{};
+        int t = from;
+        while (t < n_scans && hit_off_host[t + 1] == hit_off_host[t]) ++t;
+        end = t;
+        if (t >= n_scans) return 0;
+        while (t < n_scans && gq.n < group_max) {
+            const int nb = hit_off_host[t + 1] - hit_off_host[t];
+            if (nb < 0) return -1;
+            if (nb > 65535) break;
+            if (nb > 0) {
+                gq.nb[gq.n] = nb; gq.origin_row[gq.n] = t; gq.hit_row[gq.n] = hit_off_host[t];
+                gq.first_block[gq.n + 1] = gq.first_block[gq.n] + blocks_of(nb);
+                ++gq.n;
+            }
+            ++t;
+        }
+        end = t;
+        return gq.n > 0 ? 1 : 0;
+    };
+    ScanGroup grp{}, nxt{};
+    bool have_nxt = false;
+    int nxt_end = 0;
     int s = 0;
     while (s < n_scans) {
         const int nb0 = hit_off_host[s + 1] - hit_off_host[s];
@@ -479,21 +745,29 @@ extern "C" int icpmi_grid_update_scans_box(float* log_odds, void* counts_ws, int
         BBox* cur = slots + (q % 3);
         if (nb0 <= 65535) {
             // a group: the following scans too, while they fit a 16-bit counter (empty scans are skipped over)
-            ScanGroup grp{};
             int t = s;
-            while (t < n_scans && grp.n < group_max) {
-                const int nb = hit_off_host[t + 1] - hit_off_host[t];
-                if (nb < 0) return ICPMI_ERR_ARG;
-                if (nb > 65535) break;
-                if (nb > 0) {
-                    grp.nb[grp.n] = nb; grp.origin_row[grp.n] = t; grp.hit_row[grp.n] = hit_off_host[t];
-                    grp.first_block[grp.n + 1] = grp.first_block[grp.n] + blocks_of(nb);
-                    ++grp.n;
-                }
-                ++t;
-            }
+            bool boxes_ready = false;
+            if (have_nxt && nxt.origin_row[0] == s) { grp = nxt; t = nxt_end; boxes_ready = true; }
+            else if (build_group(s, grp, t) < 0) return ICPMI_ERR_ARG;
+            have_nxt = false;
             const int blocks = grp.first_block[grp.n];
-            if (pending) ray_step_kernel<<<blocks + RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, origins, hits, grp, counts, cells, cur, blocks, fin);
+            if (tiles_ok) {
+                ta.boxes = nullptr;
+                if (live_scans > 1) {                               // several scans share the window: each one's own box
+                    ScanBox* boxes = box_sets + (size_t)(q & 1) * RC_GROUP_MAX * RT_BOXES;
+                    if (!boxes_ready) ray_scan_boxes_kernel<<<grp.n, RT_THREADS, 0, st>>>(g, origins, hits, grp, boxes);
+                    ta.boxes = boxes;
+                    const int r = build_group(t, nxt, nxt_end);     // the boxes of the group after this one ride on this launch
+                    if (r < 0) return ICPMI_ERR_ARG;
+                    have_nxt = r > 0;
+                }
+                const int n_items = grp.n * rt_blocks_per_scan(ta.tiles_x * ta.tiles_y);
+                const int n_tiles = n_items < rt_wgs ? n_items : rt_wgs;
+                const int n_fin = pending ? RC_FIN_BLOCKS : 0;
+                if (!have_nxt) nxt.n = 0;
+                ray_tile_step_kernel<<<n_tiles + n_fin + nxt.n, RT_THREADS, 0, st>>>(g, origins, hits, grp, counts, cells, cur, ta, n_items, n_tiles, n_fin,
+                                                                                     fin, nxt, box_sets + (size_t)((q + 1) & 1) * RC_GROUP_MAX * RT_BOXES);
+            } else if (pending) ray_step_kernel<<<blocks + RC_FIN_BLOCKS, RC_THREADS, 0, st>>>(g, origins, hits, grp, counts, cells, cur, blocks, fin);
             else ray_count_group_kernel<<<blocks, RC_THREADS, 0, st>>>(g, origins, hits, grp, counts, cells, cur);
             // this group's finalisation: reads its own grids and slot, frees the slot two groups ahead
             fin.counts = counts; fin.n_grids = grp.n; fin.bbox = cur; fin.other = slots + ((q + 2) % 3);

@@ -313,7 +313,15 @@ def test_world_to_grid(umap):
 GRID_KW = dict(resolution=0.05, p_hit=0.85, p_miss=0.42, log_odds_min=-8.0, log_odds_max=8.0)
 
 
-def test_update_scan_small_grid_bit_exact(umap):
+@pytest.fixture(params=["tiles", "atomic"])
+def raypath(request, monkeypatch):
+    """Both counting passes of the ray-cast: per tile in LDS (the default for a replay of several scans whose box the
+    caller knows) and integer atomics per (beam, cell) on the scan's counter grid (single scans, callers without a box)."""
+    monkeypatch.setenv("ICPMI_RAYCAST", request.param)      # "tiles" also sends single scans down the tile pass
+    return request.param
+
+
+def test_update_scan_small_grid_bit_exact(umap, raypath):
     z = load_golden("grid")
     b = z["small_bounds"]
     g = umap.OccupancyGrid2D(b[0], b[1], b[2], b[3], **GRID_KW)
@@ -331,7 +339,7 @@ def test_update_scan_small_grid_bit_exact(umap):
     assert np.array_equal(g.log_odds, z["small_after40"])
 
 
-def test_update_scan_edges_defaults_display(umap):
+def test_update_scan_edges_defaults_display(umap, raypath):
     z = load_golden("grid")
     b = z["small_bounds"]
     g = umap.OccupancyGrid2D(b[0], b[1], b[2], b[3], **GRID_KW)
@@ -366,7 +374,7 @@ def test_log_odds_host_view_is_read_only_and_assignment_uploads(umap):
     assert np.array_equal(g.log_odds, ref) and ref.max() == 8.0
 
 
-def test_update_scan_config4_full_grid(umap):
+def test_update_scan_config4_full_grid(umap, raypath):
     z = load_golden("grid")
     b = z["cfg4_bounds"]
     g = umap.OccupancyGrid2D(b[0], b[1], b[2], b[3], **GRID_KW)
@@ -377,7 +385,7 @@ def test_update_scan_config4_full_grid(umap):
     assert np.array_equal(nz, z["cfg4_nz_idx"]) and np.array_equal(lo[nz], z["cfg4_nz_val"])
 
 
-def test_update_scan_clip_semantics_and_wide_scans(umap):
+def test_update_scan_clip_semantics_and_wide_scans(umap, raypath):
     rng = np.random.default_rng(5)
     # clamp range that excludes 0: the first scan clips EVERY cell, like np.clip on the whole grid
     g = umap.OccupancyGrid2D(-2.0, 2.0, -2.0, 2.0, resolution=0.1, log_odds_min=0.5, log_odds_max=3.0)
@@ -404,7 +412,57 @@ def test_update_scan_clip_semantics_and_wide_scans(umap):
     assert np.array_equal(g3.log_odds, ref)
 
 
-def test_raycast_full_size_properties(umap):
+def test_raycast_lattice_of_hits_all_slopes_and_ties(umap, raypath):
+    """Hits on every cell centre of a lattice around the origin: every slope m / D with D <= 23, among them the ones that
+    sit exactly on the boundary between two cells of a column (2 k m = (2 j + 1) D), beams of length zero, axis and
+    diagonal beams, duplicates; origin on a tile corner, a tile edge and inside a tile."""
+    res = 0.1
+    for ocell in ((64, 64), (63, 70), (100, 37), (3, 2)):
+        g = umap.OccupancyGrid2D(0.0, 14.0, 0.0, 11.0, resolution=res, p_hit=0.7, p_miss=0.4)
+        ox, oy = (ocell[0] + 0.5) * res, (ocell[1] + 0.5) * res
+        jj, ii = np.meshgrid(np.arange(-23, 24), np.arange(-23, 24))
+        hits = np.stack([ox + ii.ravel() * res, oy + jj.ravel() * res], axis=1)
+        hits = np.vstack([hits, hits[::7]])                                  # duplicates
+        ref = np.zeros((g.ny, g.nx), dtype=np.float32)
+        for _ in range(2):
+            g.update_scan([ox, oy], hits)
+            oracle.grid_update_scan(ref, g.min_x, g.min_y, res, [ox, oy], hits, g.l_hit, g.l_miss, -5.0, 5.0)
+        assert np.array_equal(g.log_odds, ref), ocell
+
+
+def test_raycast_scan_sizes_and_random_geometry(umap, raypath):
+    """Scans of 1 .. 9 000 beams (beam chunks of every size), origins inside and outside the grid, beams that leave the
+    grid or start and end outside it, a few non-finite coordinates."""
+    rng = np.random.default_rng(33)
+    g = umap.OccupancyGrid2D(-10.0, 10.0, -6.0, 7.0, resolution=0.05, p_hit=0.8, p_miss=0.35, log_odds_min=-6.0, log_odds_max=6.0)
+    ref = np.zeros((g.ny, g.nx), dtype=np.float32)
+    sizes = [1, 2, 63, 300, 512, 513, 2048, 2049, 4096, 4100, 8192, 9000]
+    origins = rng.uniform(-9, 9, size=(len(sizes), 2)) * np.array([1.0, 0.6])
+    origins[3] = [-12.0, 1.0]                                               # outside the grid
+    origins[7] = [2.0, 9.0]
+    scans = []
+    for n, o in zip(sizes, origins):
+        ang = rng.uniform(0, 2 * np.pi, size=n)
+        rad = rng.uniform(0.0, 14.0, size=n) * (rng.random(n) < 0.9)        # a tenth of the beams have length zero
+        scans.append(o + np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=1))
+    for o, h in zip(origins, scans):                                        # one by one: the live path
+        g.update_scan(o, h)
+        oracle.grid_update_scan(ref, g.min_x, g.min_y, 0.05, o, h, g.l_hit, g.l_miss, -6.0, 6.0)
+        assert np.array_equal(g.log_odds, ref), len(h)
+    g2 = umap.OccupancyGrid2D(-10.0, 10.0, -6.0, 7.0, resolution=0.05, p_hit=0.8, p_miss=0.35, log_odds_min=-6.0, log_odds_max=6.0)
+    g2.update_scans(origins, scans)                                         # the replay path: groups of mixed sizes
+    assert np.array_equal(g2.log_odds, ref)
+    bad = scans[4].copy()
+    bad[5, 0] = np.nan
+    bad[9, 1] = np.inf
+    g3 = umap.OccupancyGrid2D(-10.0, 10.0, -6.0, 7.0, resolution=0.05)
+    g3.update_scan(origins[4], np.delete(bad, [5, 9], axis=0))
+    g4 = umap.OccupancyGrid2D(-10.0, 10.0, -6.0, 7.0, resolution=0.05)
+    g4.update_scan(origins[4], bad)                                         # beams with a non-finite end are dropped
+    assert np.array_equal(g3.log_odds, g4.log_odds)
+
+
+def test_raycast_full_size_properties(umap, raypath):
     """Config-4 sized grid, 200 scans: size-independent checks beside the oracle on a sample."""
     from icpmi import synth
     p0 = (0.3, -0.2, np.deg2rad(10.0))
@@ -428,7 +486,7 @@ def test_raycast_full_size_properties(umap):
     assert np.array_equal(g.log_odds, ref)
 
 
-def test_band_replay_equals_whole_replay(umap):
+def test_band_replay_equals_whole_replay(umap, raypath):
     """every band of rows replayed on its own (as one rank of a sharded replay would) and the
     bands put together = the unsharded replay = the oracle, bit for bit; rows outside a band stay untouched."""
     from icpmi import dist as idist, synth
@@ -955,7 +1013,7 @@ def test_voxel_all_three_sort_paths(uicp):
         assert np.array_equal(uicp.voxel_downsample(cloud3, voxel), oracle.voxel_downsample(cloud3, voxel)), voxel
 
 
-def test_replay_groups_with_wide_and_empty_scans(umap):
+def test_replay_groups_with_wide_and_empty_scans(umap, raypath):
     """A replay whose groups of 16 scans are interrupted by a scan with more beams than a 16-bit counter holds (two-round
     path, flushes the pending group) and by empty scans (skipped, not clipped): equal to the scans applied one by one."""
     from icpmi import synth

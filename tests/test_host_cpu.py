@@ -37,7 +37,7 @@ def test_library_builds_and_exports_header_symbols():
     assert lib.icpmi_version().decode().startswith("icpmi")
     assert lib.icpmi_strerror(-2).decode() == "workspace missing or too small"
     # host-only size queries (no GPU touched)
-    assert lib.icpmi_grid_workspace_bytes(10, 20) == 4 * 10 * 20 * 4 + 256           # four grids of counters + box slots (was 32 grids)
+    assert lib.icpmi_grid_workspace_bytes(10, 20) == 4 * 10 * 20 * 4 + 256 + 2 * 32 * 17 * 16   # four grids of counters (was 32) + box slots + per-scan cell boxes
     assert lib.icpmi_icp_workspace_bytes(2, 100, 2) == 2 * 100 * (16 + 8 + 4) + 256
     assert lib.icpmi_voxel_workspace_bytes(2048) == 256
     assert lib.icpmi_voxel_workspace_bytes(100000) > 100000 * 24
