@@ -179,7 +179,7 @@ __device__ __forceinline__ void accumulate_step(double* ctrl, const double (&r)[
 }
 
 template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT>
-__global__ __launch_bounds__(THREADS, 4) void icp2_fused_kernel(Icp2Args a) {   // 4 waves/SIMD: 2 x 512 or 1 x 1024 per CU
+__global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_kernel(Icp2Args a) {   // 4 waves/SIMD: 2 x 512 or 1 x 1024 per CU; 6: 2 x 768
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ double redA[red_doubles<11>()];         // normal equations (10) / centroid sums (5) + carried squared error
     __shared__ double redB[red_doubles<4>()];          // cross-covariance
@@ -596,19 +596,19 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     int T2 = 0, SM2 = 0;                // second launch for the pairs the first shape cannot hold
     const bool many = n_pairs >= 1024;
     if (T == 0) {
-        // A voxel-filtered 2 048-beam scan keeps ~1 400 rows: 512 threads x 3 rows, two workgroups per CU — one pair's
-        // serial solve and barrier waits overlap the other's search.  Clouds that keep more than 1 536 rows go to a
-        // second launch (1 024 threads).  With few pairs (less than two per CU) 1 024 threads x 2 rows finish a pair
-        // soonest.
+        // A voxel-filtered 2 048-beam scan keeps ~1 400 rows: 768 threads x 2 rows, two workgroups per CU (6 waves per
+        // SIMD at 80 registers; 512 x 3 at 4 waves per SIMD is 5 % slower) — one pair's serial solve and barrier waits
+        // overlap the other's search.  Clouds that keep more than 1 536 rows go to a second launch (1 024 threads).
+        // With few pairs (less than two per CU) 1 024 threads x 2 rows finish a pair soonest.
         if (max_src_n <= 1024) { T = 512; SM = 2; }
-        else if (many) { T = 512; SM = 3; }
+        else if (many) { T = 768; SM = 2; }
         else if (max_src_n <= 2048) { T = 1024; SM = 2; }
         else { T = 1024; SM = 4; }
     }
     // LDS copy of the target: 36 B per point, 48 B with the float32 images of the filter.  Two workgroups of the
     // 512-thread shapes share a CU only up to 1 536 filter points (2 x 73.7 KB): larger targets, like larger
     // sources, are left to the second launch.  The filter needs <= 2 048 points (96 KB, one workgroup per CU).
-    int cap1 = (T == 512 && many && in_lds && want_filter && max_tgt_n > 1536) ? 1536 : max_tgt_n;
+    int cap1 = ((T == 512 || T == 768) && many && in_lds && want_filter && max_tgt_n > 1536) ? 1536 : max_tgt_n;
     if (T * SM < max_src_n || cap1 < max_tgt_n) { T2 = 1024; SM2 = max_src_n <= 2048 ? 2 : 4; a.skip_over = 1; }
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
@@ -624,6 +624,7 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
         if (T == 512 && SM == 2) ICPMI_ICP2_GO(512, 2);
         else if (T == 512 && SM == 3) ICPMI_ICP2_GO(512, 3);
         else if (T == 512 && SM == 4) ICPMI_ICP2_GO(512, 4);
+        else if (T == 768 && SM == 2) ICPMI_ICP2_GO(768, 2);
         else if (T == 1024 && SM == 2) ICPMI_ICP2_GO(1024, 2);
         else if (T == 1024 && SM == 4) ICPMI_ICP2_GO(1024, 4);
         else return ICPMI_ERR_ARG;
