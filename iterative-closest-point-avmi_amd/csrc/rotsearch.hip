@@ -65,14 +65,36 @@ __global__ void rs_offsets_kernel(int32_t* off, int n_src, int n_tgt) {
 
 // np.mean(cloud, axis=0) of a C-contiguous (n, 2) array adds the rows one after the other (the reduction runs
 // along the slow axis: no pairwise summation) and divides by n: one lane per (cloud, column).
-__global__ void rs_means_kernel(const double* __restrict__ vox, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
-                                int centred, double shift_x, double shift_y, double* __restrict__ rec) {
-    const int t = threadIdx.x;
-    if (t < 4) {
-        const int c = t >> 1, d = t & 1, n = cnt[c];
-        const double* p = vox + (size_t)off[c] * 2 + d;
-        double s = 0.0;
-        for (int i = 0; i < n; ++i) s += p[2 * i];
+// Two waves, one per cloud: the wave copies 256 rows at a time into LDS with coalesced loads (the chain of
+// dependent adds then never waits for HBM) and its lanes 0 and 1 add the two columns in row order.
+constexpr int RS_MEAN_ROWS = 256;
+__global__ __launch_bounds__(2 * ICPMI_WAVE) void rs_means_kernel(const double* __restrict__ vox, const int32_t* __restrict__ off,
+                                                                 const int32_t* __restrict__ cnt, int centred, double shift_x,
+                                                                 double shift_y, double* __restrict__ rec) {
+    __shared__ double2 rows[2][RS_MEAN_ROWS];
+    const int c = wave_id(), lane = lane_id(), n = cnt[c];
+    const double2* p = reinterpret_cast<const double2*>(vox + (size_t)off[c] * 2);
+    double s = 0.0;
+    for (int i0 = 0; i0 < n; i0 += RS_MEAN_ROWS) {                       // wave-uniform trip count
+        const int m = min(RS_MEAN_ROWS, n - i0);
+        for (int i = lane; i < m; i += ICPMI_WAVE) rows[c][i] = p[i0 + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 2) {
+            const double* col = reinterpret_cast<const double*>(rows[c]) + lane;
+            int i = 0;
+            for (; i + 8 <= m; i += 8) {
+                const double v0 = col[2 * i], v1 = col[2 * i + 2], v2 = col[2 * i + 4], v3 = col[2 * i + 6];
+                const double v4 = col[2 * i + 8], v5 = col[2 * i + 10], v6 = col[2 * i + 12], v7 = col[2 * i + 14];
+                s += v0; s += v1; s += v2; s += v3; s += v4; s += v5; s += v6; s += v7;
+            }
+            for (; i < m; ++i) s += col[2 * i];
+        }
+        __builtin_amdgcn_wave_barrier();                                 // the rows are read before the next copy overwrites them
+    }
+    if (lane < 2) {
+        const int d = lane;
         const double m = s / (double)n;
         if (c == 0) rec[RSREC_MUS + d] = centred ? m : 0.0;
         else rec[RSREC_MUT + d] = centred ? m : (d == 0 ? shift_x : shift_y);
@@ -81,18 +103,45 @@ __global__ void rs_means_kernel(const double* __restrict__ vox, const int32_t* _
 }
 
 // np.argmin: the first minimum, or the first NaN if there is one.  All threads of the workgroup get the answer.
+// Every thread takes a strided share (first smallest value and first NaN of its share), the waves reduce by
+// (value, index) and thread 0 settles the few wave results: no chain of dependent loads.  sh: 3 ints per wave + 1.
+constexpr int RS_ARGMIN_INTS = 3 * 16 + 1;
 __device__ __forceinline__ int first_argmin(const double* __restrict__ v, int n, int* sh) {
-    if (threadIdx.x == 0) {
-        int best = 0;
-        bool nan_seen = false;
-        for (int i = 0; i < n && !nan_seen; ++i) {
-            if (v[i] != v[i]) { best = i; nan_seen = true; }
-            else if (v[i] < v[best]) best = i;
-        }
-        *sh = best;
+    const int big = 0x7fffffff;
+    double bv = __builtin_inf();
+    int bi = big, bn = big;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double x = v[i];
+        if (x != x) bn = min(bn, i);
+        else if (x < bv) { bv = x; bi = i; }                 // ascending i: the first of equal values stays
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ov = __shfl_xor(bv, o, ICPMI_WAVE);
+        const int oi = __shfl_xor(bi, o, ICPMI_WAVE), on = __shfl_xor(bn, o, ICPMI_WAVE);
+        if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        bn = min(bn, on);
+    }
+    double* shv = reinterpret_cast<double*>(sh);             // value per wave (2 ints each), then indices
+    const int waves = (blockDim.x + ICPMI_WAVE - 1) / ICPMI_WAVE;
+    int* shi = sh + 2 * 16;
+    if (lane_id() == 0) { shv[wave_id()] = bv; shi[wave_id()] = bi; atomicMin(&sh[3 * 16], bn); }
     __syncthreads();
-    return *sh;
+    int best = 0;
+    if (sh[3 * 16] != big) best = sh[3 * 16];                // np.argmin: the first NaN wins
+    else {
+        double gv = __builtin_inf();
+        int gi = big;
+        for (int w = 0; w < waves; ++w)
+            if (shv[w] < gv || (shv[w] == gv && shi[w] < gi)) { gv = shv[w]; gi = shi[w]; }
+        best = gi == big ? 0 : gi;                           // nothing below +inf: index 0, as the serial scan
+    }
+    __syncthreads();                                         // sh may be used again
+    return best;
+}
+__device__ __forceinline__ void first_argmin_init(int* sh) {
+    if (threadIdx.x == 0) sh[3 * 16] = 0x7fffffff;
+    __syncthreads();
 }
 
 // score of one angle per workgroup, clouds and centroids read from the device: table == nullptr: angle a of
@@ -103,12 +152,13 @@ __global__ __launch_bounds__(RS_THREADS) void rotation_scores_state_kernel(
     const double* __restrict__ prev_scores, int n_prev, double* __restrict__ scores) {
     __shared__ __attribute__((aligned(16))) double tile[RS_TILE_DOUBLES];
     __shared__ double red[block_sum_doubles<1>()];
-    __shared__ int sh_k;
+    __shared__ __attribute__((aligned(8))) int sh_k[RS_ARGMIN_INTS];
     block_sum_init(red, block_sum_doubles<1>());
     const int a = blockIdx.x;
     const int n = cnt[0], m = cnt[1];
     if (table_cnt) {
-        const int k = first_argmin(prev_scores, n_prev, &sh_k);
+        first_argmin_init(sh_k);
+        const int k = first_argmin(prev_scores, n_prev, sh_k);
         if (a >= table_cnt[k]) { if (threadIdx.x == 0) scores[a] = __builtin_inf(); return; }
         cs += (size_t)k * table_stride * 2;
     }
@@ -144,11 +194,12 @@ __global__ __launch_bounds__(RS_THREADS) void rotation_scores_state_kernel(
 
 __global__ void rs_finish_kernel(const double* __restrict__ coarse, int n_coarse, const double* __restrict__ fine,
                                  const int32_t* __restrict__ fine_cnt, double* __restrict__ rec) {
-    __shared__ int sh;
-    const int k = first_argmin(coarse, n_coarse, &sh);
-    __syncthreads();
+    __shared__ __attribute__((aligned(8))) int sh[RS_ARGMIN_INTS];
+    first_argmin_init(sh);
+    const int k = first_argmin(coarse, n_coarse, sh);
     const int nf = fine_cnt ? fine_cnt[k] : 0;
-    const int j = nf > 0 ? first_argmin(fine, nf, &sh) : 0;
+    first_argmin_init(sh);
+    const int j = nf > 0 ? first_argmin(fine, nf, sh) : 0;
     if (threadIdx.x == 0) {
         rec[RSREC_K] = (double)k; rec[RSREC_CSCORE] = coarse[k];
         rec[RSREC_NF] = (double)nf; rec[RSREC_J] = (double)j; rec[RSREC_FSCORE] = nf > 0 ? fine[j] : __builtin_nan("");
@@ -201,7 +252,7 @@ extern "C" int icpmi_rotation_search(const double* pts, int32_t n_src, int32_t n
     const int32_t off_host[3] = {0, n_src, n_src + n_tgt};                  // read before the call returns
     int rc = icpmi_voxel_downsample_batch(pts, off, off_host, 2, 2, voxel_size, vox, cnt, vws, icpmi_voxel_workspace_bytes(mx), stream);
     if (rc != ICPMI_OK) return rc;
-    rs_means_kernel<<<1, 64, 0, st>>>(vox, off, cnt, centred, shift_x, shift_y, out_record);
+    rs_means_kernel<<<1, 2 * ICPMI_WAVE, 0, st>>>(vox, off, cnt, centred, shift_x, shift_y, out_record);
     rotation_scores_state_kernel<<<n_coarse, RS_THREADS, 0, st>>>(vox, off, cnt, out_record, coarse_cs, nullptr, 0, nullptr, 0, sc_coarse);
     if (max_fine > 0)
         rotation_scores_state_kernel<<<max_fine, RS_THREADS, 0, st>>>(vox, off, cnt, out_record, fine_cs, fine_cnt, max_fine, sc_coarse,
