@@ -95,8 +95,11 @@ def pmc_traffic(kernel_substr, workgroups):
     key = [k for k in doc.get("kernels", {}) if kernel_substr in k and f"[{workgroups} workgroups]" in k]
     if not key:
         return None, "kernel/grid not in the committed PMC summary"
-    return doc["kernels"][key[0]]["hbm_bytes_per_launch"], (f"profiles/{os.path.basename(PMC_TRAFFIC)} (2 x FETCH_SIZE + "
-                                                            "WRITE_SIZE, KiB -> bytes; same csrc signature)")
+    # a batch with a few wide clouds is two launches of the same grid (the second registers only those pairs): the
+    # dominant one is the one that moves the bytes
+    best = max(key, key=lambda k: doc["kernels"][k]["hbm_bytes_per_launch"])
+    return doc["kernels"][best]["hbm_bytes_per_launch"], (f"profiles/{os.path.basename(PMC_TRAFFIC)} (2 x FETCH_SIZE + "
+                                                          "WRITE_SIZE, KiB -> bytes; same csrc signature)")
 
 
 class Leg:
