@@ -126,9 +126,13 @@ int icpmi_p2l_solve_2d(const double* src, int32_t n_src, const double* tgt, cons
  * clouds of this batch.  With it, 2-D pairs whose source has at most 4096 rows
  * run on the fast kernel (exact sweep search on the axis-sorted target copy —
  * staged in LDS up to 4096 target rows, read in place through L2 above; pair
- * state in registers; `normals` and `workspace` are then not read).  Without
- * it, or for 3-D / larger sources, the exhaustive LDS-tiled kernel runs and
- * needs `workspace` (and `normals` for point_to_line).  Results agree. */
+ * state in registers; `normals` is then not read, and `workspace` is optional:
+ * given, a point_to_line batch of >= 1024 pairs runs in two stages — every pair
+ * up to 12 iterations, then the pairs still running, parked there with their
+ * moving rows and matches, together in a second launch — which gives the same
+ * results bit for bit, sooner).  Without `prepared`, or for 3-D / larger
+ * sources, the exhaustive LDS-tiled kernel runs and needs `workspace` (and
+ * `normals` for point_to_line).  Results agree. */
 size_t icpmi_icp_workspace_bytes(int32_t n_pairs, int32_t max_src_n, int32_t dim);
 int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
                     const double* normals, const void* prepared,

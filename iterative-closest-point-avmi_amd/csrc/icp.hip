@@ -314,7 +314,7 @@ extern "C" size_t icpmi_icp_workspace_bytes(int32_t n_pairs, int32_t max_src_n, 
 namespace icpmi {
 int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const int32_t* ps, const int32_t* pt,
                 int n_pairs, int max_src_n, int max_tgt_n, int total_rows, const icpmi_icp_params* p, const double* init,
-                double* results, const void* prepared, hipStream_t st);   // icp2.hip
+                double* results, const void* prepared, void* workspace, size_t workspace_bytes, hipStream_t st);   // icp2.hip
 }
 
 extern "C" int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const int32_t* cnt_dev,
@@ -333,7 +333,7 @@ extern "C" int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const 
     // fast path: prepared (axis-sorted) targets, everything on chip
     if (prepared && p->dim == 2 && max_src_n <= 4096)
         return launch_icp2(pts, off_dev, cnt_dev, pair_src, pair_tgt, n_pairs, max_src_n, max_tgt_n, total_rows, p, init,
-                           results, prepared, st);
+                           results, prepared, workspace, workspace_bytes, st);
     if (p->method == ICPMI_POINT_TO_LINE && p->dim == 2 && !normals) return ICPMI_ERR_ARG;
     if (!workspace || workspace_bytes < icpmi_icp_workspace_bytes(n_pairs, max_src_n, p->dim)) return ICPMI_ERR_WORKSPACE;
     const size_t rows = (size_t)n_pairs * (size_t)max_src_n;

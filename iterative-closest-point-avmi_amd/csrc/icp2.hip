@@ -62,7 +62,18 @@ struct Icp2Args {
     int has_init;
     int n_lo, m_lo;           // second launch: only the pairs whose source has more than n_lo rows or whose target more than m_lo
     int skip_over;            // first launch: leave pairs beyond THREADS x SMAX source rows or lds_points target rows to the second
+    // Two-stage run of a large batch (launch_icp2): the first launch takes every pair up to it_limit iterations and
+    // parks the ones still running (moving rows, matches, totals); the second continues exactly those, all started
+    // together, instead of the last of them finishing alone at the end of one long launch.
+    int it_begin, it_limit;   // iterations [it_begin, min(it_limit, max_iterations)) run here
+    int resume;               // 1: the pairs are list[0 .. *list_count), their state comes from st_*
+    double2* st_xy;           // [pair][st_stride]: moving source rows of a parked pair
+    int32_t* st_pos;          //                    and the position of each row's match in the sorted target
+    int32_t* list;
+    int32_t* list_count;
+    int st_stride;
 };
+constexpr int ICP2_ST_PARKED = 100;     // internal status between the two stages
 
 // ── workgroup sums of NV values per thread ───────────────────────────────────────────────────────────
 // Per wave, a TRANSPOSING reduction: v_permlane32_swap exchanges the upper half of one register with the lower
@@ -178,15 +189,14 @@ __device__ __forceinline__ void accumulate_step(double* ctrl, const double (&r)[
     ctrl[CTRL_TT] = (tt0 * r[0] + tt1 * r[1]) + t[0]; ctrl[CTRL_TT + 1] = (tt0 * r[2] + tt1 * r[3]) + t[1];
 }
 
-template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT>
-__global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_kernel(Icp2Args a) {   // 4 waves/SIMD: 2 x 512 or 1 x 1024 per CU; 6: 2 x 768
+template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT, bool RESUME>
+__device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ double redA[red_doubles<11>()];         // normal equations (10) / centroid sums (5) + carried squared error
     __shared__ double redB[red_doubles<4>()];          // cross-covariance
     __shared__ double ctrl[CTRL_DOUBLES];
     constexpr int NWAVES = THREADS / ICPMI_WAVE;
 
-    const int b = blockIdx.x;
     const int tid = threadIdx.x;
     const bool lead = tid < ICPMI_WAVE;                      // wave 0 carries the uniform state
     const int sc = a.pair_src[b], tc = a.pair_tgt[b];
@@ -213,12 +223,20 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
     if (FILT && tid == 0) rt_bits = 0;
 
     if (tid == 0) {
-        const double* in = a.init + (size_t)b * 6;          // icp.py:153-156
-        ctrl[CTRL_RT] = a.has_init ? in[0] : 1.0; ctrl[CTRL_RT + 1] = a.has_init ? in[1] : 0.0;
-        ctrl[CTRL_RT + 2] = a.has_init ? in[2] : 0.0; ctrl[CTRL_RT + 3] = a.has_init ? in[3] : 1.0;
-        ctrl[CTRL_TT] = a.has_init ? in[4] : 0.0; ctrl[CTRL_TT + 1] = a.has_init ? in[5] : 0.0;
-        ctrl[CTRL_ERR] = __builtin_inf(); ctrl[CTRL_PREV] = __builtin_inf(); ctrl[CTRL_DELTA] = __builtin_inf();
-        ctrl[CTRL_ITERS] = 0.0; ctrl[CTRL_STATUS] = (double)ICPMI_ST_MAXITER;
+        if (RESUME) {                                       // the totals the first stage left in the result record
+            ctrl[CTRL_RT] = res[0]; ctrl[CTRL_RT + 1] = res[1]; ctrl[CTRL_RT + 2] = res[2]; ctrl[CTRL_RT + 3] = res[3];
+            ctrl[CTRL_TT] = res[ICPMI_RES_T]; ctrl[CTRL_TT + 1] = res[ICPMI_RES_T + 1];
+            ctrl[CTRL_ERR] = res[ICPMI_RES_ERR]; ctrl[CTRL_PREV] = res[ICPMI_RES_ERR]; ctrl[CTRL_DELTA] = res[ICPMI_RES_DELTA];
+            ctrl[CTRL_ITERS] = res[ICPMI_RES_ITERS];
+        } else {
+            const double* in = a.init + (size_t)b * 6;      // icp.py:153-156
+            ctrl[CTRL_RT] = a.has_init ? in[0] : 1.0; ctrl[CTRL_RT + 1] = a.has_init ? in[1] : 0.0;
+            ctrl[CTRL_RT + 2] = a.has_init ? in[2] : 0.0; ctrl[CTRL_RT + 3] = a.has_init ? in[3] : 1.0;
+            ctrl[CTRL_TT] = a.has_init ? in[4] : 0.0; ctrl[CTRL_TT + 1] = a.has_init ? in[5] : 0.0;
+            ctrl[CTRL_ERR] = __builtin_inf(); ctrl[CTRL_PREV] = __builtin_inf(); ctrl[CTRL_DELTA] = __builtin_inf();
+            ctrl[CTRL_ITERS] = 0.0;
+        }
+        ctrl[CTRL_STATUS] = (double)ICPMI_ST_MAXITER;
     }
 
     if (N <= 0 || M <= 0 || dir < 0 || (TGT_LDS && M > a.lds_points) || N > THREADS * ICP2_SMAX || (!FILT && dir >= SWEEP_POLAR)) {
@@ -284,7 +302,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
         for (int s = 0; s < ICP2_SMAX; ++s) {
             const int n = s * THREADS + tid;
             px[s] = 0.0; py[s] = 0.0; pos[s] = -1;                       // -1: no previous match yet
-            if (n < N) {
+            if (n < N && RESUME) {
+                const double2 v = a.st_xy[(size_t)b * a.st_stride + n];
+                px[s] = v.x; py[s] = v.y; pos[s] = a.st_pos[(size_t)b * a.st_stride + n];
+            } else if (n < N) {
                 const double x = src[2 * n], y = src[2 * n + 1];
                 if (a.has_init) {                           // source @ R_init.T + t_init
                     const double* in = a.init + (size_t)b * 6;
@@ -308,11 +329,26 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
         }
 
         double e_part = 0.0;          // this thread's share of the squared error of the step just applied
+        if (RESUME) {
+            // the squared residual of the last step of the first stage against the matches it used: the sums of the
+            // apply loop below, term by term
+#pragma unroll
+            for (int s = 0; s < ICP2_SMAX; ++s) {
+                if (!(s < S && s * THREADS + tid < N)) continue;
+                const double2 q = sxy[pos[s]];
+                const double ex = q.x - px[s], ey = q.y - py[s];
+                double se = 0.0;
+                se += ex * ex;
+                se += ey * ey;
+                e_part += se;
+            }
+        }
         bool stopped = false;
 #ifdef ICPMI_DIAG
         double dg_nn = 0, dg_red = 0, dg_lead = 0, dg_apply = 0;
 #endif
-        for (int it = 0; it < a.max_iterations; ++it) {
+        const int it_end = RESUME ? a.max_iterations : min(a.max_iterations, a.it_limit);
+        for (int it = RESUME ? a.it_begin : 0; it < it_end; ++it) {
             DIAG_T(c0);
             // ── correspondences: exact sweep search in LDS, icp.py:179 ───────
             // A row whose net displacement since its last search is inside its budget keeps one of its two
@@ -525,7 +561,21 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
             if (tid == 0) { res[4] = dg_nn; res[5] = dg_red; res[6] = dg_lead; res[7] = dg_apply; }
 #endif
         }
-        if (!stopped && a.max_iterations > 0) {
+        if (!RESUME && !stopped && it_end < a.max_iterations) {
+            // parked for the second stage: rows and matches as they are, totals through the result record
+#pragma unroll
+            for (int s = 0; s < ICP2_SMAX; ++s) {
+                const int n = s * THREADS + tid;
+                if (s < S && n < N) {
+                    a.st_xy[(size_t)b * a.st_stride + n] = make_double2(px[s], py[s]);
+                    a.st_pos[(size_t)b * a.st_stride + n] = pos[s];
+                }
+            }
+            if (tid == 0) {
+                ctrl[CTRL_STATUS] = (double)ICP2_ST_PARKED;
+                a.list[atomicAdd(a.list_count, 1)] = b;
+            }
+        } else if (!stopped && a.max_iterations > 0) {
             // the last step's error has not been reduced yet: icp.py:215-223 for it = max_iterations - 1
             double e[1] = {e_part};
             __syncthreads();                      // redA may still be read by the lead wave of the last iteration
@@ -556,11 +606,29 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
     }
 }
 
+template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT>
+__global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_kernel(Icp2Args a) {   // 4 waves/SIMD: 2 x 512 or 1 x 1024 per CU; 6: 2 x 768
+    icp2_pair<THREADS, ICP2_SMAX, TGT_LDS, FILT, false>(a, blockIdx.x);                              // one pair per workgroup
+}
+
+// second stage of a two-stage run: the workgroups walk the list of parked pairs
+template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT>
+__global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_resume_kernel(Icp2Args a) {
+    const int count = *a.list_count;
+    for (int j = blockIdx.x; j < count; j += gridDim.x) {
+        // the pair index in a scalar register: everything addressed through it stays scalar
+        icp2_pair<THREADS, ICP2_SMAX, TGT_LDS, FILT, true>(a, __builtin_amdgcn_readfirstlane(a.list[j]));
+        __syncthreads();                                    // LDS is staged again for the next pair
+    }
+}
+
 // host side: called by icpmi_icp_batch (icp.hip) when a prepared buffer is given and everything fits
 int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const int32_t* ps, const int32_t* pt,
                 int n_pairs, int max_src_n, int max_tgt_n, int total_rows, const icpmi_icp_params* p, const double* init,
-                double* results, const void* prepared, hipStream_t st) {
+                double* results, const void* prepared, void* workspace, size_t workspace_bytes, hipStream_t st) {
     Icp2Args a;
+    a.it_begin = 0; a.it_limit = 0x7fffffff; a.resume = 0;
+    a.st_xy = nullptr; a.st_pos = nullptr; a.list = nullptr; a.list_count = nullptr; a.st_stride = 0;
     const unsigned char* b = (const unsigned char*)prepared;
     a.pts = pts; a.off = off; a.cnt = cnt; a.pair_src = ps; a.pair_tgt = pt; a.init = init; a.results = results;
     a.g_sxy = (const double2*)b;
@@ -591,6 +659,13 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
         if (hipFuncSetAttribute((const void*)icp2_fused_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                 (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                                   \
         icp2_fused_kernel<TT, SS, L, F><<<n_pairs, TT, lds, st>>>(a);                                                             \
+        if (two_stage && pass == 0) {                       /* the parked pairs, all started together */                         \
+            Icp2Args c = a;                                                                                                      \
+            c.resume = 1; c.it_begin = a.it_limit; c.it_limit = 0x7fffffff;                                                      \
+            if (hipFuncSetAttribute((const void*)icp2_resume_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                    (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                               \
+            icp2_resume_kernel<TT, SS, L, F><<<stage2_grid, TT, lds, st>>>(c);                                                   \
+        }                                                                                                                        \
     } while (0)
     a.n_lo = -1; a.m_lo = 0; a.skip_over = 0;
     int T2 = 0, SM2 = 0;                // second launch for the pairs the first shape cannot hold
@@ -610,7 +685,31 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     // sources, are left to the second launch.  The filter needs <= 2 048 points (96 KB, one workgroup per CU).
     int cap1 = ((T == 512 || T == 768) && many && in_lds && want_filter && max_tgt_n > 1536) ? 1536 : max_tgt_n;
     if (T * SM < max_src_n || cap1 < max_tgt_n) { T2 = 1024; SM2 = max_src_n <= 2048 ? 2 : 4; a.skip_over = 1; }
+    // Two stages for a large batch (see Icp2Args): needs the caller's workspace for the parked state.  About one pair
+    // in thirteen of a loop-closure batch runs to the iteration limit; 12 iterations settle the others.
+    // ICPMI_ICP2_STAGES=1 keeps one launch (experiments, and the test that both give the same bits).
+    constexpr int STAGE1_ITERATIONS = 12;                   // measured 6.12 / 5.42 / 5.36 / 5.38 / 5.39 ms at 8 / 10 / 12 / 14 / 16
+    const char* senv = getenv("ICPMI_ICP2_STAGES");
+    const size_t st_rows = (size_t)n_pairs * (size_t)max_src_n;
+    const size_t st_bytes = st_rows * 20 + (size_t)n_pairs * 4 + 64;
+    // point-to-line only: its pairs either settle within ~10 iterations or circle to the limit; point-to-point pairs all
+    // take 25-40 and would all be parked (ICPMI_ICP2_STAGES=2 forces the stages for them too: tests)
+    const bool two_stage = many && workspace && workspace_bytes >= st_bytes && p->max_iterations >= 2 * STAGE1_ITERATIONS &&
+                           !(senv && senv[0] == '1') && (p->method == ICPMI_POINT_TO_LINE || (senv && senv[0] == '2'));
+    // second-stage workgroups: a sixteenth of the pairs (about one pair in thirteen is parked; measured 5.37 / 5.25 /
+    // 5.51 ms at an eighth / a sixteenth / a thirty-second of 16 384 pairs), each walking the list
+    const int stage2_grid = n_pairs / 16 > 256 ? n_pairs / 16 : 256;
+    if (two_stage) {
+        unsigned char* w = (unsigned char*)workspace;
+        a.st_xy = (double2*)w;
+        a.st_pos = (int32_t*)(w + st_rows * 16);
+        a.list = (int32_t*)(w + st_rows * 20);
+        a.list_count = a.list + n_pairs;
+        a.st_stride = max_src_n;
+        if (hipMemsetAsync(a.list_count, 0, sizeof(int32_t), st) != hipSuccess) return ICPMI_ERR_HIP;
+    }
     for (int pass = 0; pass < 2; ++pass) {
+        a.it_limit = two_stage && pass == 0 ? STAGE1_ITERATIONS : 0x7fffffff;
         if (pass == 1) {
             if (!T2) break;
             a.n_lo = T * SM; a.m_lo = cap1; a.skip_over = 0; T = T2; SM = SM2; cap1 = max_tgt_n;

@@ -998,6 +998,41 @@ def test_large_batch_with_wide_clouds_takes_the_second_launch(uicp):
         assert int(res[i, 14]) == io["iters"] and rot_err(res[i, :4].reshape(2, 2), res[i, 9:11], Ro, to) < FRO_TOL
 
 
+def test_two_stage_run_of_a_large_batch_is_the_single_launch_bit_for_bit(uicp, monkeypatch):
+    """A batch of >= 1 024 pairs runs the fused ICP kernel in two stages: everybody up to 12 iterations, then the pairs
+    still running — parked with their moving rows, matches and totals — together in a second launch (so that the
+    150-iteration pairs do not finish alone at the end of one long launch).  The continuation searches afresh, finds
+    the same matches and sums the same terms in the same order: every result double equals the single launch's."""
+    from icpmi import batch, synth
+    B = 1100
+    srcs, tgts = synth.loop_closure_batch(B, seed0=61000)
+    rng = np.random.default_rng(8)
+    th = rng.uniform(-0.05, 0.05, size=B)
+    R0 = np.stack([np.stack([np.cos(th), -np.sin(th)], -1), np.stack([np.sin(th), np.cos(th)], -1)], -2)
+    t0 = rng.uniform(-0.05, 0.05, size=(B, 2))
+    cases = [dict(method="point_to_line", max_iterations=150, max_corr_dist=None, init=None),
+             dict(method="point_to_line", max_iterations=24, max_corr_dist=0.5, init=(R0, t0)),
+             dict(method="point_to_point", max_iterations=60, max_corr_dist=1.0, init=None)]
+    for case in cases:
+        out = {}
+        for stages in ("1", "2"):
+            monkeypatch.setenv("ICPMI_ICP2_STAGES", stages)
+            kw = dict(error_threshold=1e-10, max_iterations=case["max_iterations"], voxel_size=0.04, method=case["method"],
+                      normal_k=12, max_corr_dist=case["max_corr_dist"])
+            if case["init"] is not None:
+                kw.update(R_init=case["init"][0], t_init=case["init"][1])
+            b = batch.IcpBatch(srcs + tgts, np.arange(B), np.arange(B, 2 * B), **kw)
+            out[stages] = b.run().cpu().numpy()[:B].copy()
+        it = out["1"][:, 14]
+        assert (it > 12).sum() > 20, case                                      # pairs that go through the second stage
+        assert case["method"] == "point_to_point" or (it <= 12).sum() > 200    # ... and (point-to-line) pairs that do not
+        assert set(np.unique(out["2"][:, 15])) <= {1.0, 2.0, 3.0}, case         # nobody is left parked
+        assert np.array_equal(out["1"], out["2"]), case
+    for i in (0, 7, 500):
+        Ro, to, eo, io = oracle.icp(srcs[i], tgts[i], 1e-10, 60, 0.04, method="point_to_point", max_corr_dist=1.0)
+        assert int(out["2"][i, 14]) == io["iters"] and rot_err(out["2"][i, :4].reshape(2, 2), out["2"][i, 9:11], Ro, to) < FRO_TOL
+
+
 def test_voxel_all_three_sort_paths(uicp):
     """voxel.hip sorts (key, row) packed in 32 bits, packed in 64 bits, or as pairs, depending on how many voxels
     the bounding box holds; all three must give np.unique's rows and order (oracle), bit for bit."""
