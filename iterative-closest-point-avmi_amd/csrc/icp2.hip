@@ -685,7 +685,9 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     // sources, are left to the second launch.  The filter needs <= 2 048 points (96 KB, one workgroup per CU).
     int cap1 = ((T == 512 || T == 768) && many && in_lds && want_filter && max_tgt_n > 1536) ? 1536 : max_tgt_n;
     if (T * SM < max_src_n || cap1 < max_tgt_n) { T2 = 1024; SM2 = max_src_n <= 2048 ? 2 : 4; a.skip_over = 1; }
-    // Two stages for a large batch (see Icp2Args): needs the caller's workspace for the parked state.  About one pair
+    // Two stages for a large batch (see Icp2Args): needs the caller's workspace for the parked state.  Below ~1 000 pairs
+    // every long pair starts within the first two rounds anyway and the stages only add their own cost (512 pairs: 0.70
+    // against 0.65 ms).  About one pair
     // in thirteen of a loop-closure batch runs to the iteration limit; 12 iterations settle the others.
     // ICPMI_ICP2_STAGES=1 keeps one launch (experiments, and the test that both give the same bits).
     constexpr int STAGE1_ITERATIONS = 12;                   // measured 6.12 / 5.42 / 5.36 / 5.38 / 5.39 ms at 8 / 10 / 12 / 14 / 16
