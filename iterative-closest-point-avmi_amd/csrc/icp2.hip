@@ -72,6 +72,8 @@ struct Icp2Args {
     int32_t* list;
     int32_t* list_count;
     int st_stride;
+    int32_t* wide_list;       // pairs the first launch leaves to the wider shape (when the caller gave a workspace): the second
+    int32_t* wide_count;      // launch walks this list instead of starting a workgroup per pair of the batch just to look
 };
 constexpr int ICP2_ST_PARKED = 100;     // internal status between the two stages
 
@@ -208,7 +210,10 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
     // The voxel filter leaves the row counts on the device, so the launcher sizes the rows per thread for the usual
     // case and sends the (rare) larger clouds to a second launch of a wider shape: each pair is registered by
     // exactly one of the two (uniform per workgroup, before any barrier).
-    if (a.skip_over ? (N > THREADS * ICP2_SMAX || (TGT_LDS && M > a.lds_points)) : (a.n_lo >= 0 && N <= a.n_lo && M <= a.m_lo)) return;
+    if (a.skip_over ? (N > THREADS * ICP2_SMAX || (TGT_LDS && M > a.lds_points)) : (a.n_lo >= 0 && N <= a.n_lo && M <= a.m_lo)) {
+        if (a.skip_over && a.wide_list && threadIdx.x == 0) a.wide_list[atomicAdd(a.wide_count, 1)] = b;
+        return;
+    }
 
     // two instantiations, each sees ONE address space behind these pointers
     double2* lds_xy = reinterpret_cast<double2*>(dyn);
@@ -611,6 +616,16 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_fused_ke
     icp2_pair<THREADS, ICP2_SMAX, TGT_LDS, FILT, false>(a, blockIdx.x);                              // one pair per workgroup
 }
 
+// the launch for wide clouds when the first one listed them: the workgroups walk that list
+template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT>
+__global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_wide_kernel(Icp2Args a) {
+    const int count = *a.wide_count;
+    for (int j = blockIdx.x; j < count; j += gridDim.x) {
+        icp2_pair<THREADS, ICP2_SMAX, TGT_LDS, FILT, false>(a, __builtin_amdgcn_readfirstlane(a.wide_list[j]));
+        __syncthreads();                                    // LDS is staged again for the next pair
+    }
+}
+
 // second stage of a two-stage run: the workgroups walk the list of parked pairs
 template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT>
 __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_resume_kernel(Icp2Args a) {
@@ -629,6 +644,7 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     Icp2Args a;
     a.it_begin = 0; a.it_limit = 0x7fffffff; a.resume = 0;
     a.st_xy = nullptr; a.st_pos = nullptr; a.list = nullptr; a.list_count = nullptr; a.st_stride = 0;
+    a.wide_list = nullptr; a.wide_count = nullptr;
     const unsigned char* b = (const unsigned char*)prepared;
     a.pts = pts; a.off = off; a.cnt = cnt; a.pair_src = ps; a.pair_tgt = pt; a.init = init; a.results = results;
     a.g_sxy = (const double2*)b;
@@ -658,7 +674,11 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     do {                                                                                                                         \
         if (hipFuncSetAttribute((const void*)icp2_fused_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                 (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                                   \
-        icp2_fused_kernel<TT, SS, L, F><<<n_pairs, TT, lds, st>>>(a);                                                             \
+        if (pass == 1 && a.wide_list) {                     /* the listed pairs, a quarter of the batch's workgroups */          \
+            if (hipFuncSetAttribute((const void*)icp2_wide_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                                    (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                               \
+            icp2_wide_kernel<TT, SS, L, F><<<(n_pairs + 3) / 4, TT, lds, st>>>(a);                                               \
+        } else icp2_fused_kernel<TT, SS, L, F><<<n_pairs, TT, lds, st>>>(a);                                                      \
         if (two_stage && pass == 0) {                       /* the parked pairs, all started together */                         \
             Icp2Args c = a;                                                                                                      \
             c.resume = 1; c.it_begin = a.it_limit; c.it_limit = 0x7fffffff;                                                      \
@@ -693,22 +713,26 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     constexpr int STAGE1_ITERATIONS = 12;                   // measured 6.12 / 5.42 / 5.36 / 5.38 / 5.39 ms at 8 / 10 / 12 / 14 / 16
     const char* senv = getenv("ICPMI_ICP2_STAGES");
     const size_t st_rows = (size_t)n_pairs * (size_t)max_src_n;
-    const size_t st_bytes = st_rows * 20 + (size_t)n_pairs * 4 + 64;
+    const size_t st_bytes = st_rows * 20 + (size_t)n_pairs * 8 + 64;
     // point-to-line only: its pairs either settle within ~10 iterations or circle to the limit; point-to-point pairs all
     // take 25-40 and would all be parked (ICPMI_ICP2_STAGES=2 forces the stages for them too: tests)
-    const bool two_stage = many && workspace && workspace_bytes >= st_bytes && p->max_iterations >= 2 * STAGE1_ITERATIONS &&
+    const bool have_ws = workspace && workspace_bytes >= st_bytes;
+    const bool two_stage = many && have_ws && p->max_iterations >= 2 * STAGE1_ITERATIONS &&
                            !(senv && senv[0] == '1') && (p->method == ICPMI_POINT_TO_LINE || (senv && senv[0] == '2'));
     // second-stage workgroups: a sixteenth of the pairs (about one pair in thirteen is parked; measured 5.37 / 5.25 /
     // 5.51 ms at an eighth / a sixteenth / a thirty-second of 16 384 pairs), each walking the list
     const int stage2_grid = n_pairs / 16 > 256 ? n_pairs / 16 : 256;
-    if (two_stage) {
+    if (have_ws && (two_stage || T2)) {
         unsigned char* w = (unsigned char*)workspace;
         a.st_xy = (double2*)w;
         a.st_pos = (int32_t*)(w + st_rows * 16);
         a.list = (int32_t*)(w + st_rows * 20);
-        a.list_count = a.list + n_pairs;
+        a.wide_list = a.list + n_pairs;
+        a.list_count = a.wide_list + n_pairs;
+        a.wide_count = a.list_count + 1;
         a.st_stride = max_src_n;
-        if (hipMemsetAsync(a.list_count, 0, sizeof(int32_t), st) != hipSuccess) return ICPMI_ERR_HIP;
+        if (!T2) { a.wide_list = nullptr; a.wide_count = nullptr; }
+        if (hipMemsetAsync(a.list_count, 0, 2 * sizeof(int32_t), st) != hipSuccess) return ICPMI_ERR_HIP;
     }
     for (int pass = 0; pass < 2; ++pass) {
         a.it_limit = two_stage && pass == 0 ? STAGE1_ITERATIONS : 0x7fffffff;
