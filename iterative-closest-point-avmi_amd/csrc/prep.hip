@@ -17,6 +17,49 @@ constexpr int PREP_MAXW = PREP_THREADS / ICPMI_WAVE;
 constexpr int PREP_MAX_POINTS = 4096;   // sorted copy (20 B/pt) + sort scratch (12 B/pt) stay in LDS
 
 // KK = capacity of the per-query neighbour list (0: no normals); GRID: k-NN through a grid instead of the sweep
+// Sort of up to E * PREP_THREADS rows by (key, row) on registers; leaves keys[i] / rows[i] = full sortable key and row of
+// the i-th smallest, like bitonic_sort_pairs.  by_row, keys: E * PREP_THREADS slots of LDS each; rows: as many.
+template <int E>
+__device__ __forceinline__ void prep_sort_regs(const double* __restrict__ P, int M, int dir, uint64_t* by_row, uint64_t* keys,
+                                               uint32_t* rows) {
+    constexpr uint64_t ROW_MASK = 0x7ff;                               // rows below 2 048
+    uint64_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = (int)threadIdx.x * E + e;
+        const uint64_t k = i < M ? f64_sortable(dir == SWEEP_POLAR ? polar_key(P[2 * i], P[2 * i + 1]) : proj(dir, P[2 * i], P[2 * i + 1])) : ~0ull;
+        by_row[i] = k;
+        v[e] = i < M ? ((k & ~ROW_MASK) | (uint64_t)i) : ~0ull;
+    }
+    bitonic_sort_regs<uint64_t, E>(v, keys);                           // ends with a barrier: by_row is complete too
+    int bad = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = (int)threadIdx.x * E + e;
+        const uint32_t r = v[e] == ~0ull ? 0xffffffffu : (uint32_t)(v[e] & ROW_MASK);
+        rows[i] = r;
+        keys[i] = r == 0xffffffffu ? ~0ull : by_row[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = (int)threadIdx.x * E + e;
+        if (i + 1 < M && (keys[i] > keys[i + 1] || (keys[i] == keys[i + 1] && rows[i] > rows[i + 1]))) bad = 1;
+    }
+    if (__syncthreads_or(bad)) {
+        // keys that agree in their upper 53 bits came out in row order: one thread puts such runs in (key, row) order
+        if (threadIdx.x == 0)
+            for (int i = 1; i < M; ++i) {
+                const uint64_t k = keys[i];
+                const uint32_t r = rows[i];
+                int j = i - 1;
+                while (j >= 0 && (keys[j] > k || (keys[j] == k && rows[j] > r))) { keys[j + 1] = keys[j]; rows[j + 1] = rows[j]; --j; }
+                keys[j + 1] = k; rows[j + 1] = r;
+            }
+        __syncthreads();
+    }
+}
+
 template <int KK, bool GRID>
 __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 16 ? 4 : 2))) void prep_targets_kernel(   // three workgroups per CU up to KK = 13, two up to 16
     const double* __restrict__ pts, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
@@ -39,22 +82,34 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
     double2* sxy = reinterpret_cast<double2*>(dyn);                                   // lds_points * 16 B
     int32_t* sorig = reinterpret_cast<int32_t*>(dyn + (size_t)lds_points * 16);       // lds_points * 4 B
     float* sth = reinterpret_cast<float*>(dyn + (size_t)lds_points * 20);             // lds_points * 4 B: float32 bearings (polar order)
-    // sort scratch (npad * 12 B): behind the sorted copy when the grid needs it afterwards, otherwise ON the sorted
-    // copy (the sorted rows pass through registers) — 32 KB instead of 56 KB for ~1 500 points, so that the k-NN
-    // loops of three workgroups instead of two share a CU
+    // sort scratch (20 B per padded slot, 12 for 4 096 slots): behind the sorted copy when the grid needs it afterwards,
+    // otherwise ON the sorted copy (the sorted rows pass through registers) — 40 KB instead of 64 KB for ~1 500 points, so
+    // that the k-NN loops of three workgroups instead of two share a CU
     const size_t scratch_at = GRID ? (size_t)lds_points * 24 : 0;
-    uint64_t* keys = reinterpret_cast<uint64_t*>(dyn + scratch_at);                   // npad * 8 B
-    uint32_t* rows = reinterpret_cast<uint32_t*>(dyn + scratch_at + (size_t)npad * 8);
+    const bool reg_sort = npad <= 4 * PREP_THREADS;                                    // the network on registers (below)
+    const int nsort = reg_sort ? max(npad, PREP_THREADS) : npad;
+    uint64_t* by_row = reinterpret_cast<uint64_t*>(dyn + scratch_at);                  // reg_sort: keys by row, nsort * 8 B
+    uint64_t* keys = reinterpret_cast<uint64_t*>(dyn + scratch_at + (reg_sort ? (size_t)nsort * 8 : 0));     // sorted keys, 8 B per slot
+    uint32_t* rows = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(keys) + (size_t)nsort * 8); // their rows
 
     double bounds[4];
     const int dir = choose_axis<PREP_THREADS>(P, M, dsc, hist, bounds, polar);
     // ── sort along the chosen axis (or by bearing) ───────────────────────────
-    for (int i = threadIdx.x; i < npad; i += PREP_THREADS) {
-        keys[i] = i < M ? f64_sortable(dir == SWEEP_POLAR ? polar_key(P[2 * i], P[2 * i + 1]) : proj(dir, P[2 * i], P[2 * i + 1])) : ~0ull;
-        rows[i] = i < M ? (uint32_t)i : 0xffffffffu;
+    if (reg_sort) {
+        // (key, row) as ONE 64-bit element: the key's low 11 bits give way to the row, the network runs on registers
+        // (sort.hpp: thread t owns slots t E .. t E + E - 1), and the rare neighbours whose keys agree in the 53 bits
+        // that are left are put right afterwards from the full keys — the order is exactly the pair sort's.
+        if (nsort == PREP_THREADS) prep_sort_regs<1>(P, M, dir, by_row, keys, rows);
+        else if (nsort == 2 * PREP_THREADS) prep_sort_regs<2>(P, M, dir, by_row, keys, rows);
+        else prep_sort_regs<4>(P, M, dir, by_row, keys, rows);
+    } else {
+        for (int i = threadIdx.x; i < npad; i += PREP_THREADS) {
+            keys[i] = i < M ? f64_sortable(dir == SWEEP_POLAR ? polar_key(P[2 * i], P[2 * i + 1]) : proj(dir, P[2 * i], P[2 * i + 1])) : ~0ull;
+            rows[i] = i < M ? (uint32_t)i : 0xffffffffu;
+        }
+        __syncthreads();
+        bitonic_sort_pairs(keys, rows, npad);
     }
-    __syncthreads();
-    bitonic_sort_pairs(keys, rows, npad);
     double2* o_sxy = g_sxy + off[c];
     int32_t* o_sorig = g_sorig + off[c];
     float* o_skey = g_skey + off[c];
@@ -92,7 +147,7 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
             // points in it).  Built in the LDS the sort has released: cell ends (4 B per cell), then positions
             // by cell.  Same neighbours, same order.
             const int cells_cap = min(4096, 2 * npad);
-            uint32_t* cell_end = reinterpret_cast<uint32_t*>(keys);
+            uint32_t* cell_end = reinterpret_cast<uint32_t*>(dyn + scratch_at);
             uint16_t* cell_pts = reinterpret_cast<uint16_t*>(cell_end + cells_cap);
             const PrepGrid grid = prep_grid_build(sxy, M, bounds, kk, cell_end, cell_pts, cells_cap, hist);
             prep_normals_grid<KK>(sxy, sorig, M, min(M, part * per), min(M, (part + 1) * per), kk, grid, o_snrm, o_rows);
@@ -250,8 +305,9 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
     // sorted copy: 20 B per point, sized to the largest cloud (rounded to 64); sort scratch: 12 B per padded slot.
     // With ~1 500-point clouds this is 53 KB instead of 64 KB: three workgroups per CU instead of two.
     const int lds_points = (small_max + 63) / 64 * 64;
-    const size_t lds_sep = (size_t)lds_points * 24 + (size_t)npad * 12;                     // grid instantiation
-    const size_t lds_alias = (size_t)lds_points * 24 > (size_t)npad * 12 ? (size_t)lds_points * 24 : (size_t)npad * 12;
+    const size_t sort_bytes = npad <= 4 * PREP_THREADS ? (size_t)(npad > PREP_THREADS ? npad : PREP_THREADS) * 20 : (size_t)npad * 12;
+    const size_t lds_sep = (size_t)lds_points * 24 + sort_bytes;                            // grid instantiation
+    const size_t lds_alias = (size_t)lds_points * 24 > sort_bytes ? (size_t)lds_points * 24 : sort_bytes;
     // bearing order (sweep.hpp, SWEEP_POLAR) only where every consumer understands it: clouds of at most 2 048 rows, on
     // request; ICPMI_POLAR=0 never, =2 always (tests); the filter being off (ICPMI_ICP2_FILTER=0) also turns it off
     int polar = allow_polar && small_max <= 2048 ? 1 : 0;
