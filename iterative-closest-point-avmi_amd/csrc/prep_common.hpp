@@ -44,12 +44,14 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
         for (int q = 0; q < MAXW; ++q) { a = fmin(a, dsc[d * MAXW + q]); b = fmax(b, dsc[(4 + d) * MAXW + q]); }
         mn[d] = a; mx[d] = b;
     }
+    double scale[4];                                       // bins per unit of the projection: one division per axis, not per point
+#pragma unroll
+    for (int d = 0; d < 4; ++d) { const double r = mx[d] - mn[d]; scale[d] = r > 0.0 ? (double)PREP_BINS / r : 0.0; }
     for (int i = threadIdx.x; i < M; i += THREADS) {
         const double x = P[2 * i], y = P[2 * i + 1];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const double r = mx[d] - mn[d];
-            int b = r > 0.0 ? (int)((proj(d, x, y) - mn[d]) / r * PREP_BINS) : 0;
+            int b = (int)((proj(d, x, y) - mn[d]) * scale[d]);
             b = b < 0 ? 0 : (b >= PREP_BINS ? PREP_BINS - 1 : b);
             atomicAdd(&hist[d * PREP_BINS + b], 1);
         }
@@ -66,22 +68,21 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
     }
     __syncthreads();
     if (bounds) { bounds[0] = mn[0]; bounds[1] = mx[0]; bounds[2] = mn[1]; bounds[3] = mx[1]; }
+    // the costs: a lane per bin (PREP_BINS = a wave), fixed-tree wave sums of integer-valued terms — every wave gets
+    // the same numbers, so every thread the same answer without another barrier
+    static_assert(PREP_BINS == ICPMI_WAVE, "one lane per bin");
     int dir = 0;
     double bestc = __builtin_inf();
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
-        double s = 0.0;
-#pragma unroll 4
-        for (int b = 0; b < PREP_BINS; ++b) { const double cn = (double)hist[d * PREP_BINS + b]; s += cn * cn; }
+        const double cn = (double)hist[d * PREP_BINS + l];
+        const double s = wave_sum(cn * cn);
         const double r = mx[d] - mn[d];
         const double cost = r > 0.0 ? (d < 2 ? 1.0 : 1.4142135623730951) * s / r : __builtin_inf();
-        if (cost < bestc) { bestc = cost; dir = d; }       // integer histogram: identical in every thread
+        if (cost < bestc) { bestc = cost; dir = d; }
     }
     if (polar) {
-        double s = 0.0;
-#pragma unroll 4
-        for (int b = 0; b < PREP_BINS; ++b)
-            s += (double)hist[4 * PREP_BINS + b] * ((double)(unsigned int)hist[5 * PREP_BINS + b] * (1.0 / 1024.0));
+        const double s = wave_sum((double)hist[4 * PREP_BINS + l] * ((double)(unsigned int)hist[5 * PREP_BINS + l] * (1.0 / 1024.0)));
         if (s * (1.0 / 6.283185307179586) < bestc || polar == 2) dir = SWEEP_POLAR;
     }
     return dir;
