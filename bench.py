@@ -92,14 +92,18 @@ def pmc_traffic(kernel_substr, workgroups):
     if doc.get("csrc_sha256") != csrc_signature():
         return None, (f"profiles/{os.path.basename(PMC_TRAFFIC)} was collected on csrc {doc.get('csrc_sha256')}, this build is "
                       f"{csrc_signature()}: stale, not quoted")
-    key = [k for k in doc.get("kernels", {}) if kernel_substr in k and f"[{workgroups} workgroups]" in k]
+    # A batch is up to three launches of the fused ICP code (csrc/icp2.hip: every pair up to 12 iterations on `workgroups`
+    # workgroups; the pairs still running, on a sixteenth as many; the pairs with wide clouds, on a thirty-second): the
+    # bytes of the batch are their sum.  kernel_substr may name several kernels ("a|b").
+    B = workgroups
+    grid_of = {"icp2_resume": max(256, B // 16), "icp2_wide": min(B, max(256, B // 32))}
+    key = [k for k in doc.get("kernels", {}) for sub in kernel_substr.split("|")
+           if sub in k and f"[{grid_of.get(sub, B)} workgroups]" in k]
     if not key:
         return None, "kernel/grid not in the committed PMC summary"
-    # a batch with a few wide clouds is two launches of the same grid (the second registers only those pairs): the
-    # dominant one is the one that moves the bytes
-    best = max(key, key=lambda k: doc["kernels"][k]["hbm_bytes_per_launch"])
-    return doc["kernels"][best]["hbm_bytes_per_launch"], (f"profiles/{os.path.basename(PMC_TRAFFIC)} (2 x FETCH_SIZE + "
-                                                          "WRITE_SIZE, KiB -> bytes; same csrc signature)")
+    total = sum(doc["kernels"][k]["hbm_bytes_per_launch"] for k in key)
+    return total, (f"profiles/{os.path.basename(PMC_TRAFFIC)} (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, summed over the "
+                   f"{len(key)} launch(es) of a batch; same csrc signature)")
 
 
 class Leg:
@@ -155,7 +159,8 @@ class Leg:
         it = local[:, _lib.RES_ITERS]
         alg_bytes = float((it * (28.0 * self.N + 16.0 * self.M)).sum())   # 16N+16M read + 12N written per pair-iteration
         achieved = alg_bytes / (self.k_ms * 1e-3) / 1e9
-        name = "icp2_fused_kernel (fused ICP, sorted-sweep search)" if b.fast else "icp_fused_kernel"
+        name = ("icp2_fused_kernel (+ icp2_resume_kernel / icp2_wide_kernel: the launches of one batch; fused ICP, "
+                "sorted-sweep search)") if b.fast else "icp_fused_kernel"
         r = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms": round(self.k_ms, 4),
              "algorithmic_bytes_per_launch": alg_bytes, "pair_iterations_per_launch": float(it.sum()),
@@ -163,7 +168,7 @@ class Leg:
                      "kernel keeps a pair on chip for all its iterations, so it is bound by its instruction stream "
                      "(VALU + divergence), not by HBM: see traffic and profiles/r02_pmc_instruction_mix.json"}
         if b.fast:
-            r["traffic"], r["traffic_source"] = pmc_traffic("icp2_", B)
+            r["traffic"], r["traffic_source"] = pmc_traffic("icp2_fused|icp2_resume|icp2_wide", B)
             if r["traffic"]:
                 r["traffic_GBps"] = round(r["traffic"] / (self.k_ms * 1e-3) / 1e9, 1)
         return r

@@ -674,10 +674,10 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     do {                                                                                                                         \
         if (hipFuncSetAttribute((const void*)icp2_fused_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
                                 (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                                   \
-        if (pass == 1 && a.wide_list) {                     /* the listed pairs, a quarter of the batch's workgroups */          \
+        if (pass == 1 && a.wide_list) {                     /* the listed pairs: few workgroups walking the list */              \
             if (hipFuncSetAttribute((const void*)icp2_wide_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                     (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                               \
-            icp2_wide_kernel<TT, SS, L, F><<<(n_pairs + 3) / 4, TT, lds, st>>>(a);                                               \
+            icp2_wide_kernel<TT, SS, L, F><<<wide_grid, TT, lds, st>>>(a);                                                       \
         } else icp2_fused_kernel<TT, SS, L, F><<<n_pairs, TT, lds, st>>>(a);                                                      \
         if (two_stage && pass == 0) {                       /* the parked pairs, all started together */                         \
             Icp2Args c = a;                                                                                                      \
@@ -722,6 +722,8 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     // second-stage workgroups: a sixteenth of the pairs (about one pair in thirteen is parked; measured 5.37 / 5.25 /
     // 5.51 ms at an eighth / a sixteenth / a thirty-second of 16 384 pairs), each walking the list
     const int stage2_grid = n_pairs / 16 > 256 ? n_pairs / 16 : 256;
+    // the launch for wide clouds: a thirty-second (a launch of 4 096 workgroups that find an empty list still takes 100 us)
+    const int wide_grid = n_pairs < 256 ? n_pairs : (n_pairs / 32 > 256 ? n_pairs / 32 : 256);
     if (have_ws && (two_stage || T2)) {
         unsigned char* w = (unsigned char*)workspace;
         a.st_xy = (double2*)w;
