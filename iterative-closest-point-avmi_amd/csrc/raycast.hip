@@ -265,6 +265,7 @@ struct FinArgs {
     float lo32, hi32;
     int count_kind;       // 0 = packed (H<<16 | M), 1 = counts are hits, 2 = counts are misses
     int clip, full_clip;
+    int use_window;       // 1: walk the caller's window (a single scan: its box IS the window) instead of the counted box
 };
 
 // K7 body; `block` of `nblocks` finalising workgroups
@@ -279,6 +280,7 @@ __device__ __forceinline__ void ray_finalize_body(const GridDesc& g, const FinAr
     int x0, y0, x1, y1;
     const BBox bb = *bbox;
     if (full_clip) { x0 = 0; y0 = g.ry0; x1 = g.nx - 1; y1 = g.ry1 - 1; }        // the whole band, also outside the counted window
+    else if (f.use_window) { x0 = g.wx0; y0 = g.wy0; x1 = g.wx1 - 1; y1 = g.wy1 - 1; }
     else {
         if (bb.inv_x0 == 0) { x0 = 0; y0 = 0; x1 = -1; y1 = -1; }
         else { x0 = g.nx - (int)bb.inv_x0; y0 = g.ny - (int)bb.inv_y0; x1 = (int)bb.x1p - 1; y1 = (int)bb.y1p - 1; }   // inside the band by construction
@@ -683,20 +685,22 @@ extern "C" int icpmi_grid_update_scans_box(float* log_odds, void* counts_ws, int
     // every call starts with empty boxes and ends with empty counter grids (each finalise pass zeroes what it
     // reads), so calls are independent of each other; scan_seq is no longer needed and ignored
     (void)scan_seq;
-    if (hipMemsetAsync(slots, 0, 3 * sizeof(BBox), st) != hipSuccess) return ICPMI_ERR_HIP;
+    int live_scans = 0;
+    for (int t = 0; t < n_scans; ++t) live_scans += hit_off_host[t + 1] > hit_off_host[t] ? 1 : 0;
+    // one scan with a box from the caller (the live update): the finalise pass walks that box, no slot to clear first
+    const bool window_is_box = live_scans == 1 && box_host && !empty_window;
+    if (!window_is_box && hipMemsetAsync(slots, 0, 3 * sizeof(BBox), st) != hipSuccess) return ICPMI_ERR_HIP;
     GridDesc g{nx, ny, min_x, min_y, resolution, wx0, wx1, wy0, wy1, wx0, wy0, wx1 - wx0, row_begin, row_end};
     if (empty_window) { g.wx1 = g.wx0; }                              // nothing is counted; the finalise pass only clips
     FinArgs fin{};
     fin.log_odds = log_odds; fin.l_hit = l_hit; fin.l_miss = l_miss; fin.lo32 = (float)lo; fin.hi32 = (float)hi;
-    fin.grid_stride = cells; fin.n_grids = 1;
+    fin.grid_stride = cells; fin.n_grids = 1; fin.use_window = window_is_box ? 1 : 0;
     // The tile path needs the caller's box (the tiles of the window are enumerated; a scan's own box, found on the
     // device, sends the other tiles home at once).  Without a box (a direct caller of the plain entry points, or
     // non-finite coordinates) the window is the whole grid and the per-beam atomic pass runs instead.
     // ICPMI_RAYCAST=atomic forces the latter (experiments, and the parity tests of both passes).
     // A single scan (the live update) also takes the atomic pass: two short launches, 21 us against 32.
     const char* rc_env = getenv("ICPMI_RAYCAST");
-    int live_scans = 0;
-    for (int t = 0; t < n_scans; ++t) live_scans += hit_off_host[t + 1] > hit_off_host[t] ? 1 : 0;
     const bool tiles_ok = box_host && !empty_window && !(rc_env && rc_env[0] == 'a') && hits && (live_scans > 1 || (rc_env && rc_env[0] == 't'));
     TileArgs ta{};
     ScanBox* box_sets = (ScanBox*)((unsigned char*)counts_ws + capacity * sizeof(uint32_t) + 256);
