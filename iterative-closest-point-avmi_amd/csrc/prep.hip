@@ -93,7 +93,7 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
     uint32_t* rows = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(keys) + (size_t)nsort * 8); // their rows
 
     double bounds[4];
-    const int dir = choose_axis<PREP_THREADS>(P, M, dsc, hist, bounds, polar);
+    const int dir = choose_axis<PREP_THREADS>(P, M, dsc, hist, bounds, polar, (!GRID && M >= 512) ? 4 : 1);   // bounds: the grid's
     // ── sort along the chosen axis (or by bearing) ───────────────────────────
     if (reg_sort) {
         // (key, row) as ONE 64-bit element: the key's low 11 bits give way to the row, the network runs on registers

@@ -20,12 +20,14 @@ constexpr int PREP_BINS = 64;
 // (no wedge there) never picks it.  polar == 2 forces it (tests).  hist: 6 * PREP_BINS ints.
 template <int THREADS>
 __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, double* dsc, int* hist, double* bounds = nullptr,
-                                           int polar = 0) {
+                                           int polar = 0, int step = 1) {
+    // step > 1: every step-th point only — the choice is an estimate of search cost, any answer is correct, and the
+    // sample is the same every run; callers that need exact `bounds` (the grid) pass 1
     constexpr int MAXW = THREADS / ICPMI_WAVE;
     double mn[4], mx[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d) { mn[d] = __builtin_inf(); mx[d] = -__builtin_inf(); }
-    for (int i = threadIdx.x; i < M; i += THREADS) {
+    for (int i = threadIdx.x * step; i < M; i += THREADS * step) {
         const double x = P[2 * i], y = P[2 * i + 1];
 #pragma unroll
         for (int d = 0; d < 4; ++d) { const double u = proj(d, x, y); mn[d] = fmin(mn[d], u); mx[d] = fmax(mx[d], u); }
@@ -47,7 +49,7 @@ __device__ __forceinline__ int choose_axis(const double* __restrict__ P, int M, 
     double scale[4];                                       // bins per unit of the projection: one division per axis, not per point
 #pragma unroll
     for (int d = 0; d < 4; ++d) { const double r = mx[d] - mn[d]; scale[d] = r > 0.0 ? (double)PREP_BINS / r : 0.0; }
-    for (int i = threadIdx.x; i < M; i += THREADS) {
+    for (int i = threadIdx.x * step; i < M; i += THREADS * step) {
         const double x = P[2 * i], y = P[2 * i + 1];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
