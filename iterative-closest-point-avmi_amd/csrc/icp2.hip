@@ -146,7 +146,11 @@ constexpr int CTRL_RT = 12, CTRL_TT = 16, CTRL_ERR = 18, CTRL_PREV = 19, CTRL_DE
 #define ICP2_PLAIN_ITERS 2      // iterations that search the plain nearest neighbour before budgets are kept
 #endif
 #ifndef ICP2_CENTRED_ITERS
-#define ICP2_CENTRED_ITERS 3    // iterations whose top-two search starts at the row's own projection; later ones walk from the kept match
+#define ICP2_CENTRED_ITERS 2    // iterations whose top-two search starts at the row's own projection; later ones walk from the kept match
+                                // (= ICP2_PLAIN_ITERS: none does; measured 5.22 / 5.13 ms at 3 / 2 for 16 384 pairs, 5.42 with 1 plain iteration)
+#endif
+#ifndef ICP2_PLAIN_CENTRED
+#define ICP2_PLAIN_CENTRED ICP2_PLAIN_ITERS     // plain iterations that start at the row's own projection
 #endif
 // THREADS x ICP2_SMAX = most source rows a pair may have on this instantiation
 // TGT_LDS: the prepared target is staged in LDS (<= 4096 points); otherwise it is read in place, through L2
@@ -393,8 +397,8 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 for (int s = 0; s < ICP2_SMAX; ++s)
                     if (srch[s]) {
                         double d2s;
-                        if constexpr (FILT) pos[s] = sweepf_nn(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], true, d2s);
-                        else pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], true, d2s);
+                        if constexpr (FILT) pos[s] = sweepf_nn(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], it < ICP2_PLAIN_CENTRED, d2s);
+                        else pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], it < ICP2_PLAIN_CENTRED, d2s);
                     }
             } else {
                 const bool centred = it < ICP2_CENTRED_ITERS;
