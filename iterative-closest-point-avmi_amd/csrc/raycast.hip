@@ -701,7 +701,12 @@ extern "C" int icpmi_grid_update_scans_box(float* log_odds, void* counts_ws, int
     // ICPMI_RAYCAST=atomic forces the latter (experiments, and the parity tests of both passes).
     // A single scan (the live update) also takes the atomic pass: two short launches, 21 us against 32.
     const char* rc_env = getenv("ICPMI_RAYCAST");
-    const bool tiles_ok = box_host && !empty_window && !(rc_env && rc_env[0] == 'a') && hits && (live_scans > 1 || (rc_env && rc_env[0] == 't'));
+    // ... and so does a replay whose box is far larger than a scan's reach (a long trajectory in one call): every scan
+    // would start four workgroups per tile of the box just to find that it does not get there (~1 000 tiles: even).
+    const long long window_tiles = (long long)((wx1 - wx0 + 63) / 64) * ((wy1 - wy0 + 63) / 64);
+    const bool forced_tiles = rc_env && rc_env[0] == 't';
+    const bool tiles_ok = box_host && !empty_window && !(rc_env && rc_env[0] == 'a') && hits &&
+                          ((live_scans > 1 && window_tiles <= 768) || forced_tiles);
     TileArgs ta{};
     ScanBox* box_sets = (ScanBox*)((unsigned char*)counts_ws + capacity * sizeof(uint32_t) + 256);
     ta.tiles_x = (wx1 - wx0 + RT_TILE - 1) / RT_TILE; ta.tiles_y = (wy1 - wy0 + RT_TILE - 1) / RT_TILE;

@@ -136,9 +136,29 @@ class OccupancyGrid2D:
             host = np.concatenate([np.asarray(h, dtype=np.float64).reshape(-1, 2) for h in hits]) if off[-1] else None
             packed = torch.from_numpy(np.ascontiguousarray(host)).to(self._dev) if host is not None else None
             if host is not None and not isinstance(origins, torch.Tensor):       # everything is on the host: no read-back
-                both = np.vstack([np.asarray(origins, dtype=np.float64).reshape(S, 2), host])
+                o_host = np.asarray(origins, dtype=np.float64).reshape(S, 2)
+                both = np.vstack([o_host, host])
                 box = self._box_of(both.min(axis=0), both.max(axis=0))
+                # A long trajectory in one call: the box of all scans is far larger than any scan's reach, and the tile
+                # pass of the library enumerates the tiles of the box per scan.  Consecutive scans lie close together, so
+                # the replay goes down in pieces of _REPLAY_PIECE scans, each with its own box (same order, same result).
+                if box is not None and S > self._REPLAY_PIECE and self._box_tiles(box) > 64:
+                    for c0 in range(0, S, self._REPLAY_PIECE):
+                        c1 = min(S, c0 + self._REPLAY_PIECE)
+                        if off[c1] == off[c0]:
+                            continue
+                        piece = np.vstack([o_host[c0:c1], host[off[c0]:off[c1]]])
+                        self._apply(org[c0:c1], packed[off[c0]:off[c1]], off[c0:c1 + 1] - off[c0], rows,
+                                    self._box_of(piece.min(axis=0), piece.max(axis=0)))
+                    return
         self._apply(org, packed, off, rows, box)
+
+    _REPLAY_PIECE = 64
+
+    @staticmethod
+    def _box_tiles(box):
+        """Tiles of 64 x 64 cells a cell box spans."""
+        return ((int(box[2]) - int(box[0])) // 64 + 1) * ((int(box[3]) - int(box[1])) // 64 + 1)
 
     def _cell_box(self, org, packed):
         """Inclusive cell bounds {x0, y0, x1, y1} of the origins and hits (host int32[4]): every ray stays inside

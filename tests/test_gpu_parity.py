@@ -462,6 +462,30 @@ def test_raycast_scan_sizes_and_random_geometry(umap, raypath):
     assert np.array_equal(g3.log_odds, g4.log_odds)
 
 
+def test_replay_of_a_long_trajectory_goes_down_in_pieces(umap, raypath):
+    """130 scans along a 60 m path in one update_scans call: the box of all of them spans 176 tiles, so the class sends
+    the replay down in pieces of 64 scans with a box each (the tile pass enumerates the tiles of the box per scan).
+    Same scans, same order: the oracle's grid bit for bit."""
+    rng = np.random.default_rng(77)
+    org = np.array([[-28.0 + 0.45 * i, -5.0 + 0.08 * i] for i in range(130)])
+    hits = []
+    for o in org:                                                 # returns 2 - 6 m around the sensor, in beam order
+        ang = np.linspace(-np.pi, np.pi, 230, endpoint=False)
+        rad = rng.uniform(2.0, 6.0, size=230)
+        hits.append(o + np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=1))
+    hits[64] = np.empty((0, 2))                                   # an empty scan at the start of a piece
+    kw = dict(resolution=0.05, p_hit=0.7, p_miss=0.4, log_odds_min=-4.0, log_odds_max=4.0)
+    g = umap.OccupancyGrid2D(-45.0, 45.0, -25.0, 25.0, **kw)
+    both = np.vstack([org] + [h for h in hits if len(h)])
+    assert g._box_tiles(g._box_of(both.min(axis=0), both.max(axis=0))) > 64 and len(hits) > 2 * g._REPLAY_PIECE
+    g.update_scans(org, hits)
+    ref = np.zeros((g.ny, g.nx), dtype=np.float32)
+    for o, h in zip(org, hits):
+        if len(h):
+            oracle.grid_update_scan(ref, g.min_x, g.min_y, 0.05, o, h, g.l_hit, g.l_miss, -4.0, 4.0)
+    assert np.array_equal(g.log_odds, ref)
+
+
 def test_raycast_full_size_properties(umap, raypath):
     """Config-4 sized grid, 200 scans: size-independent checks beside the oracle on a sample."""
     from icpmi import synth
