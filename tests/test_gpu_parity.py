@@ -1057,6 +1057,21 @@ def test_two_stage_run_of_a_large_batch_is_the_single_launch_bit_for_bit(uicp, m
         assert int(out["2"][i, 14]) == io["iters"] and rot_err(out["2"][i, :4].reshape(2, 2), out["2"][i, 9:11], Ro, to) < FRO_TOL
 
 
+def test_two_stage_run_with_nobody_parked(uicp):
+    """A large batch whose pairs all settle at once (source = target): the first stage finishes everybody, the list of
+    parked pairs stays empty and the second launch has nothing to do."""
+    from icpmi import batch, synth
+    B = 1024
+    srcs, _ = synth.loop_closure_batch(8, seed0=70000)
+    clouds = [srcs[i % 8] for i in range(B)]
+    b = batch.IcpBatch(clouds + clouds, np.arange(B), np.arange(B, 2 * B), error_threshold=1e-10, max_iterations=150,
+                       voxel_size=0.04, method="point_to_line", normal_k=12)
+    res = b.run().cpu().numpy()[:B]
+    assert (res[:, 15] == 1).all() and (res[:, 14] <= 3).all()                 # converged, at once
+    assert np.abs(res[:, :4] - np.array([1.0, 0.0, 0.0, 1.0])).max() < 1e-12 and np.abs(res[:, 9:11]).max() < 1e-12
+    assert np.array_equal(res[:8], res[8:16])                                  # the same pair gives the same bits wherever it sits
+
+
 def test_voxel_all_three_sort_paths(uicp):
     """voxel.hip sorts (key, row) packed in 32 bits, packed in 64 bits, or as pairs, depending on how many voxels
     the bounding box holds; all three must give np.unique's rows and order (oracle), bit for bit."""
