@@ -641,6 +641,28 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_resume_k
     }
 }
 
+// A stream of the library's own and the two events of a fork / join around it: one per host thread and device, made
+// on first use (ICPMI_ICP2_SIDE=0: never; then everything stays on the caller's stream).
+struct Icp2Side {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    int device = -1;
+    bool failed = false;
+    bool ok() {
+        int dev = -1;
+        if (failed || hipGetDevice(&dev) != hipSuccess) return false;
+        if (stream && dev == device) return true;
+        const char* e = getenv("ICPMI_ICP2_SIDE");
+        if (e && e[0] == '0') { failed = true; return false; }
+        if (stream) { (void)hipStreamDestroy(stream); (void)hipEventDestroy(fork); (void)hipEventDestroy(join); stream = nullptr; }
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) { failed = true; stream = nullptr; return false; }
+        device = dev;
+        return true;
+    }
+};
+
 // host side: called by icpmi_icp_batch (icp.hip) when a prepared buffer is given and everything fits
 int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const int32_t* ps, const int32_t* pt,
                 int n_pairs, int max_src_n, int max_tgt_n, int total_rows, const icpmi_icp_params* p, const double* init,
@@ -681,8 +703,13 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
         if (pass == 1 && a.wide_list) {                     /* the listed pairs: few workgroups walking the list */              \
             if (hipFuncSetAttribute((const void*)icp2_wide_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                     (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                               \
-            icp2_wide_kernel<TT, SS, L, F><<<wide_grid, TT, lds, st>>>(a);                                                       \
+            hipStream_t ws = st;                            /* beside the second stage when the side stream is there */          \
+            if (forked && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess) ws = side.stream;                          \
+            icp2_wide_kernel<TT, SS, L, F><<<wide_grid, TT, lds, ws>>>(a);                                                       \
+            if (ws != st && (hipEventRecord(side.join, ws) != hipSuccess || hipStreamWaitEvent(st, side.join, 0) != hipSuccess)) \
+                return ICPMI_ERR_HIP;                                                                                            \
         } else icp2_fused_kernel<TT, SS, L, F><<<n_pairs, TT, lds, st>>>(a);                                                      \
+        if (two_stage && pass == 0 && a.wide_list && side.ok()) forked = hipEventRecord(side.fork, st) == hipSuccess;            \
         if (two_stage && pass == 0) {                       /* the parked pairs, all started together */                         \
             Icp2Args c = a;                                                                                                      \
             c.resume = 1; c.it_begin = a.it_limit; c.it_limit = 0x7fffffff;                                                      \
@@ -740,6 +767,10 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
         if (!T2) { a.wide_list = nullptr; a.wide_count = nullptr; }
         if (hipMemsetAsync(a.list_count, 0, 2 * sizeof(int32_t), st) != hipSuccess) return ICPMI_ERR_HIP;
     }
+    // The launch for wide clouds (a handful of pairs, ~0.1 ms at a few per cent of the chip) only needs the first stage's
+    // list: it runs on a side stream beside the second stage and joins the caller's stream afterwards.
+    static thread_local Icp2Side side;
+    bool forked = false;
     for (int pass = 0; pass < 2; ++pass) {
         a.it_limit = two_stage && pass == 0 ? STAGE1_ITERATIONS : 0x7fffffff;
         if (pass == 1) {
