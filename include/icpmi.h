@@ -10,8 +10,13 @@
  *
  * Conventions
  *  - Every pointer is a DEVICE pointer (e.g. torch.Tensor.data_ptr()) unless the
- *    parameter name ends in _host.  Nothing is allocated, freed or retained by
- *    the library; scratch memory is passed in as a workspace.
+ *    parameter name ends in _host.  No device memory is allocated, freed or
+ *    retained by the library; scratch memory is passed in as a workspace.
+ *  - Process-wide state, all of it listed under "library state" below: the
+ *    ICPMI_* option switches (read from the environment once, at first use) and
+ *    up to three side streams per device that launchers use to overlap the
+ *    independent launches of one call (made on first use, destroyed by
+ *    icpmi_shutdown).  Calls may come from several host threads.
  *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*).
  *  - Return value: ICPMI_OK (0) or a negative ICPMI_ERR_* code; no exceptions
  *    cross the boundary.  Launch-time HIP errors are reported as ICPMI_ERR_HIP.
@@ -70,6 +75,22 @@ typedef struct icpmi_icp_params {
 
 const char* icpmi_version(void);
 const char* icpmi_strerror(int code);
+
+/* ---- library state --------------------------------------------------------
+ * Options are experiment / test switches (none is needed in production); each is
+ * read from the environment variable ICPMI_<NAME> ONCE, when the library first
+ * looks at an option, and icpmi_set_option overrides it afterwards (value NULL
+ * unsets).  Names (with or without the ICPMI_ prefix): ICP2_SIDE (0: no side
+ * streams), ICP2_SHAPE ("TxS": workgroup shape of the fused ICP), ICP2_FILTER
+ * (0: no float32 filter), ICP2_STAGES (1: one launch, 2: two stages also for
+ * point_to_point), ICP2_SPLIT (sub-batches of a small batch: 1 = off), ICP2_TAIL
+ * (0: no tail shape), POLAR (0 never / 2 always the bearing order), PREP_KNN
+ * (grid | sweep), RAYCAST (atomic | tiles | owner), RT_WGS, RS_BATCH.  Unknown
+ * names: ICPMI_ERR_ARG.  Must not race with running calls.
+ * icpmi_shutdown synchronises and destroys the side streams and events the
+ * library made (they are made again on demand); call it before unloading. */
+int icpmi_set_option(const char* name, const char* value);
+int icpmi_shutdown(void);
 
 /* ---- voxel_downsample, utilities/icp.py:117-129 --------------------------
  * For every cloud c: keys floor((p - min_c) / voxel) per axis, lexicographic

@@ -14,6 +14,26 @@
 
 namespace icpmi {
 
+// ── process-wide state (state.hip): options read once, side streams of the library ───────────────────
+// option("NAME"): value of the ICPMI_NAME switch (environment at first use, icpmi_set_option later) or nullptr.
+const char* option(const char* name);
+constexpr int ICPMI_SIDE_STREAMS = 3;
+struct Side {
+    hipStream_t stream[ICPMI_SIDE_STREAMS] = {nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr;
+    hipEvent_t join[ICPMI_SIDE_STREAMS] = {nullptr, nullptr, nullptr};
+    bool failed = false;
+};
+// Holds the library's side-stream lock for a whole fork / launch / join sequence; `side` is the current device's
+// set (made on first use) or nullptr when side streams are off or could not be made.
+struct SideLock {
+    Side* side;
+    SideLock();
+    ~SideLock();
+    SideLock(const SideLock&) = delete;
+    SideLock& operator=(const SideLock&) = delete;
+};
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (ICPMI_WAVE - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 

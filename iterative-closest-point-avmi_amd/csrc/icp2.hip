@@ -641,28 +641,6 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_resume_k
     }
 }
 
-// A stream of the library's own and the two events of a fork / join around it: one per host thread and device, made
-// on first use (ICPMI_ICP2_SIDE=0: never; then everything stays on the caller's stream).
-struct Icp2Side {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    int device = -1;
-    bool failed = false;
-    bool ok() {
-        int dev = -1;
-        if (failed || hipGetDevice(&dev) != hipSuccess) return false;
-        if (stream && dev == device) return true;
-        const char* e = getenv("ICPMI_ICP2_SIDE");
-        if (e && e[0] == '0') { failed = true; return false; }
-        if (stream) { (void)hipStreamDestroy(stream); (void)hipEventDestroy(fork); (void)hipEventDestroy(join); stream = nullptr; }
-        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) { failed = true; stream = nullptr; return false; }
-        device = dev;
-        return true;
-    }
-};
-
 // host side: called by icpmi_icp_batch (icp.hip) when a prepared buffer is given and everything fits
 int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const int32_t* ps, const int32_t* pt,
                 int n_pairs, int max_src_n, int max_tgt_n, int total_rows, const icpmi_icp_params* p, const double* init,
@@ -681,14 +659,14 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     a.error_threshold = p->error_threshold; a.max_corr_dist = p->max_corr_dist;
     a.max_iterations = p->max_iterations; a.method = p->method; a.has_init = p->has_init;
     const bool in_lds = max_tgt_n <= 4096;
-    // Workgroup shape by source size (rows per thread bounded by the instantiation).  ICPMI_ICP2_SHAPE = "TxS"
+    // Workgroup shape by source size (rows per thread bounded by the instantiation).  option ICP2_SHAPE = "TxS"
     // (threads x rows per thread, one of the instantiations below) overrides the choice for experiments;
-    // ICPMI_ICP2_FILTER=0 turns the single-precision filter off.
+    // option ICP2_FILTER = 0 turns the single-precision filter off.
     int T = 0, SM = 0;
-    if (const char* env = getenv("ICPMI_ICP2_SHAPE")) {
+    if (const char* env = option("ICP2_SHAPE")) {
         if (sscanf(env, "%dx%d", &T, &SM) != 2) { T = 0; SM = 0; }
     }
-    const char* fenv = getenv("ICPMI_ICP2_FILTER");
+    const char* fenv = option("ICP2_FILTER");
     const bool want_filter = !(fenv && fenv[0] == '0');
 #define ICPMI_ICP2_GO(TT, SS)                                                                                                    \
     do {                                                                                                                         \
@@ -704,12 +682,15 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
             if (hipFuncSetAttribute((const void*)icp2_wide_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                                     (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                               \
             hipStream_t ws = st;                            /* beside the second stage when the side stream is there */          \
-            if (forked && hipStreamWaitEvent(side.stream, side.fork, 0) == hipSuccess) ws = side.stream;                          \
+            if (forked && hipStreamWaitEvent(side->stream[0], side->fork, 0) == hipSuccess) ws = side->stream[0];                 \
             icp2_wide_kernel<TT, SS, L, F><<<wide_grid, TT, lds, ws>>>(a);                                                       \
-            if (ws != st && (hipEventRecord(side.join, ws) != hipSuccess || hipStreamWaitEvent(st, side.join, 0) != hipSuccess)) \
+            if (ws != st && (hipEventRecord(side->join[0], ws) != hipSuccess ||                                                  \
+                             hipStreamWaitEvent(st, side->join[0], 0) != hipSuccess)) {                                          \
+                (void)hipStreamSynchronize(ws);             /* never return with a launch the caller cannot order against */     \
                 return ICPMI_ERR_HIP;                                                                                            \
+            }                                                                                                                    \
         } else icp2_fused_kernel<TT, SS, L, F><<<n_pairs, TT, lds, st>>>(a);                                                      \
-        if (two_stage && pass == 0 && a.wide_list && side.ok()) forked = hipEventRecord(side.fork, st) == hipSuccess;            \
+        if (two_stage && pass == 0 && a.wide_list && side) forked = hipEventRecord(side->fork, st) == hipSuccess;                \
         if (two_stage && pass == 0) {                       /* the parked pairs, all started together */                         \
             Icp2Args c = a;                                                                                                      \
             c.resume = 1; c.it_begin = a.it_limit; c.it_limit = 0x7fffffff;                                                      \
@@ -740,13 +721,13 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     // every long pair starts within the first two rounds anyway and the stages only add their own cost (512 pairs: 0.70
     // against 0.65 ms).  About one pair
     // in thirteen of a loop-closure batch runs to the iteration limit; 12 iterations settle the others.
-    // ICPMI_ICP2_STAGES=1 keeps one launch (experiments, and the test that both give the same bits).
+    // option ICP2_STAGES = 1 keeps one launch (experiments, and the test that both give the same bits).
     constexpr int STAGE1_ITERATIONS = 12;                   // measured 6.12 / 5.42 / 5.36 / 5.38 / 5.39 ms at 8 / 10 / 12 / 14 / 16
-    const char* senv = getenv("ICPMI_ICP2_STAGES");
+    const char* senv = option("ICP2_STAGES");
     const size_t st_rows = (size_t)n_pairs * (size_t)max_src_n;
     const size_t st_bytes = st_rows * 20 + (size_t)n_pairs * 8 + 64;
     // point-to-line only: its pairs either settle within ~10 iterations or circle to the limit; point-to-point pairs all
-    // take 25-40 and would all be parked (ICPMI_ICP2_STAGES=2 forces the stages for them too: tests)
+    // take 25-40 and would all be parked (ICP2_STAGES = 2 forces the stages for them too: tests)
     const bool have_ws = workspace && workspace_bytes >= st_bytes;
     const bool two_stage = many && have_ws && p->max_iterations >= 2 * STAGE1_ITERATIONS &&
                            !(senv && senv[0] == '1') && (p->method == ICPMI_POINT_TO_LINE || (senv && senv[0] == '2'));
@@ -769,7 +750,9 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     }
     // The launch for wide clouds (a handful of pairs, ~0.1 ms at a few per cent of the chip) only needs the first stage's
     // list: it runs on a side stream beside the second stage and joins the caller's stream afterwards.
-    static thread_local Icp2Side side;
+    // (state.hip: the library's side streams, one set per device; the lock is held for the fork / launch / join sequence)
+    SideLock side_lock;
+    Side* const side = side_lock.side;
     bool forked = false;
     for (int pass = 0; pass < 2; ++pass) {
         a.it_limit = two_stage && pass == 0 ? STAGE1_ITERATIONS : 0x7fffffff;

@@ -308,17 +308,20 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
     const size_t sort_bytes = npad <= 4 * PREP_THREADS ? (size_t)(npad > PREP_THREADS ? npad : PREP_THREADS) * 20 : (size_t)npad * 12;
     const size_t lds_sep = (size_t)lds_points * 24 + sort_bytes;                            // grid instantiation
     const size_t lds_alias = (size_t)lds_points * 24 > sort_bytes ? (size_t)lds_points * 24 : sort_bytes;
-    // bearing order (sweep.hpp, SWEEP_POLAR) only where every consumer understands it: clouds of at most 2 048 rows, on
-    // request; ICPMI_POLAR=0 never, =2 always (tests); the filter being off (ICPMI_ICP2_FILTER=0) also turns it off
-    int polar = allow_polar && small_max <= 2048 ? 1 : 0;
-    if (const char* env = getenv("ICPMI_POLAR")) polar = polar ? (env[0] == '0' ? 0 : (env[0] == '2' ? 2 : 1)) : 0;
-    if (const char* env = getenv("ICPMI_ICP2_FILTER")) polar = env[0] == '0' ? 0 : polar;
+    // bearing order (sweep.hpp, SWEEP_POLAR) only where every consumer understands it: on request, and only when EVERY
+    // selected cloud has at most 2 048 rows — the fused ICP launch picks ONE instantiation for the whole batch from the
+    // same max_n, and the ones for larger targets (no float32 images) cannot walk a bearing order: a batch that mixes
+    // scans with one rolling submap therefore sorts everything along projections.  Option "POLAR": 0 never, 2 always
+    // (tests); the filter being off (option "ICP2_FILTER" = 0) also turns it off.
+    int polar = allow_polar && max_n <= 2048 ? 1 : 0;
+    if (const char* env = option("POLAR")) polar = polar ? (env[0] == '0' ? 0 : (env[0] == '2' ? 2 : 1)) : 0;
+    if (const char* env = option("ICP2_FILTER")) polar = env[0] == '0' ? 0 : polar;
     int split = 256 / n_sel;                 // a workgroup for every CU when the batch is small
     split = split < 1 ? 1 : (split > 16 ? 16 : split);
-    // k-NN search of the normals: grid for few clouds, sweep for many (see the kernel); ICPMI_PREP_KNN=grid|sweep
+    // k-NN search of the normals: grid for few clouds, sweep for many (see the kernel); option PREP_KNN = grid | sweep
     // forces one of the two (tests run both on the same inputs)
     int use_grid = split > 1;
-    if (const char* env = getenv("ICPMI_PREP_KNN")) use_grid = env[0] == 'g' ? 1 : (env[0] == 's' ? 0 : use_grid);
+    if (const char* env = option("PREP_KNN")) use_grid = env[0] == 'g' ? 1 : (env[0] == 's' ? 0 : use_grid);
 #define ICPMI_PREP_GO2(KKV, G)                                                                                          \
     do {                                                                                                                \
         const size_t lds = G ? lds_sep : lds_alias;                                                                     \

@@ -700,7 +700,7 @@ extern "C" int icpmi_grid_update_scans_box(float* log_odds, void* counts_ws, int
     // non-finite coordinates) the window is the whole grid and the per-beam atomic pass runs instead.
     // ICPMI_RAYCAST=atomic forces the latter (experiments, and the parity tests of both passes).
     // A single scan (the live update) also takes the atomic pass: two short launches, 21 us against 32.
-    const char* rc_env = getenv("ICPMI_RAYCAST");
+    const char* rc_env = option("RAYCAST");
     // ... and so does a replay whose box is far larger than a scan's reach (a long trajectory in one call): every scan
     // would start four workgroups per tile of the box just to find that it does not get there (~1 000 tiles: even).
     const long long window_tiles = (long long)((wx1 - wx0 + 63) / 64) * ((wy1 - wy0 + 63) / 64);
@@ -710,7 +710,7 @@ extern "C" int icpmi_grid_update_scans_box(float* log_odds, void* counts_ws, int
     TileArgs ta{};
     ScanBox* box_sets = (ScanBox*)((unsigned char*)counts_ws + capacity * sizeof(uint32_t) + 256);
     ta.tiles_x = (wx1 - wx0 + RT_TILE - 1) / RT_TILE; ta.tiles_y = (wy1 - wy0 + RT_TILE - 1) / RT_TILE;
-    const char* wg_env = getenv("ICPMI_RT_WGS");
+    const char* wg_env = option("RT_WGS");
     const int rt_wgs = wg_env && atoi(wg_env) > 0 ? atoi(wg_env) : 1536;      // resident workgroups of the tile pass (6 per CU)
     bool pending = false;            // a counted group whose finalisation rides on the next launch
     int64_t q = 0;                   // index of the next group (counter-grid set q&1, box slot q%3)

@@ -42,6 +42,8 @@ _SIGS = {
     # name: (restype, argtypes)
     "icpmi_version": (C.c_char_p, []),
     "icpmi_strerror": (C.c_char_p, [C.c_int]),
+    "icpmi_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "icpmi_shutdown": (C.c_int, []),
     "icpmi_voxel_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "icpmi_voxel_downsample_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -111,3 +113,14 @@ def lib():
 def check(code, what):
     if code != OK:
         raise IcpmiError(f"{what}: {lib().icpmi_strerror(code).decode()} ({code})")
+
+
+def set_option(name, value):
+    """icpmi_set_option: change one of the library's ICPMI_* switches after it has read the environment (None unsets)."""
+    check(lib().icpmi_set_option(name.encode(), None if value is None else str(value).encode()), f"set_option({name})")
+
+
+def shutdown():
+    """icpmi_shutdown: destroy the side streams and events the library made (made again on demand)."""
+    if _lib is not None:
+        check(_lib.icpmi_shutdown(), "shutdown")

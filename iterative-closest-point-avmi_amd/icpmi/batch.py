@@ -326,16 +326,20 @@ class PairContext:
 
     def __init__(self, dev):
         self.dev = dev
-        self.cap = 0
+        self.cap_s = self.cap_t = 0
         self.batch = None
 
-    def _grow(self, rows):
-        self.cap = max(4096, 2 * rows)
-        half = self.cap // 2
-        dummy = CloudSet(torch.zeros((self.cap, 2), dtype=torch.float64, device=self.dev),
-                         np.array([0, half, self.cap], dtype=np.int32))
+    def _grow(self, ns, nt):
+        # source and target capacities grow independently, each at most PREP_MAX_POINTS rows, so the batch object always
+        # takes the on-chip kernels (a 2 100-row scan against a 3 000-row target: 5 100 rows in all, both halves fit)
+        self.cap_s = min(PREP_MAX_POINTS, max(2048, self.cap_s, 2 * ns))
+        self.cap_t = min(PREP_MAX_POINTS, max(2048, self.cap_t, 2 * nt))
+        cap = self.cap_s + self.cap_t
+        dummy = CloudSet(torch.zeros((cap, 2), dtype=torch.float64, device=self.dev),
+                         np.array([0, self.cap_s, cap], dtype=np.int32))
         self.batch = IcpBatch(dummy, [0], [1], 1e-6, 1, 1.0, np.eye(2), np.zeros(2), "point_to_line", 1, None)
-        self.stage = torch.empty((self.cap, 2), dtype=torch.float64).pin_memory()
+        assert self.batch.fast, "PairContext must stay on the sorted-sweep kernels"
+        self.stage = torch.empty((cap, 2), dtype=torch.float64).pin_memory()
         self.off_stage = torch.zeros(3, dtype=torch.int32).pin_memory()
         self.init_stage = torch.zeros((1, 6), dtype=torch.float64).pin_memory()
         self.res_host = torch.zeros((1, _lib.RES_DOUBLES), dtype=torch.float64).pin_memory()
@@ -344,8 +348,8 @@ class PairContext:
               max_corr_dist):
         """-> one (RES_DOUBLES,) float64 result record on the host."""
         ns, nt = len(source), len(target)
-        if ns + nt > self.cap:
-            self._grow(ns + nt)
+        if ns > self.cap_s or nt > self.cap_t:
+            self._grow(ns, nt)
         b = self.batch
         h = self.stage.numpy()
         h[:ns] = source

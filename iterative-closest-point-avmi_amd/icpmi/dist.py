@@ -35,8 +35,11 @@ def slots_per_rank(n_pairs, world):
     return (n_pairs + world - 1) // world
 
 
-def gather_results(local, n_pairs, rank, world, group=None):
+def gather_results(local, n_pairs, rank, world, group=None, force_collective=False):
     """all_gather the per-rank result records and put them back in pair order.
+
+    force_collective: run the collective even with one rank (a world of one still goes through RCCL; the GPU test
+    uses it to load the backend on the one GPU a test box has).
 
     local: [len(shard(...)), RES_DOUBLES] float64 tensor (device for nccl, CPU
     for gloo).  Returns an [n_pairs, RES_DOUBLES] tensor on the same device,
@@ -48,7 +51,7 @@ def gather_results(local, n_pairs, rank, world, group=None):
     k = len(shard(n_pairs, rank, world))
     if k:
         padded[:k] = local[:k]
-    if world == 1:
+    if world == 1 and not force_collective:
         return padded[:n_pairs]
     out = torch.empty((world * per, width), dtype=torch.float64, device=local.device)
     _all_gather_into(out, padded, group)
@@ -147,11 +150,12 @@ def row_bands(ny, world, cost=None):
     return b
 
 
-def gather_bands(band, bands, rank, world, group=None):
-    """all_gather the ranks' bands (rows bands[r]:bands[r+1]) into the full (ny, nx) grid, on band's device."""
+def gather_bands(band, bands, rank, world, group=None, force_collective=False):
+    """all_gather the ranks' bands (rows bands[r]:bands[r+1]) into the full (ny, nx) grid, on band's device.
+    force_collective: as in gather_results."""
     nx = band.shape[1]
     ny = bands[-1]
-    if world == 1:
+    if world == 1 and not force_collective:
         return band
     rows = max(bands[r + 1] - bands[r] for r in range(world))
     padded = torch.zeros((rows, nx), dtype=band.dtype, device=band.device)

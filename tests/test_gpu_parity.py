@@ -129,7 +129,7 @@ def test_normals_sizes(uicp):
         assert np.abs(np.abs(np.sum(n * no, axis=1)) - 1).max() < 1e-9, (m, k)
 
 
-def test_normals_grid_and_sweep_searches_agree(uicp, monkeypatch):
+def test_normals_grid_and_sweep_searches_agree(uicp, libopt):
     """prep.hip has two exact k-NN searches (grid for few clouds, sweep for many): same neighbours in the same order,
     so the normals are bit-identical; ICPMI_PREP_KNN forces either on the same inputs."""
     from icpmi import synth
@@ -144,7 +144,7 @@ def test_normals_grid_and_sweep_searches_agree(uicp, monkeypatch):
         for k in (12, 5, 31):
             got = {}
             for mode in ("grid", "sweep"):
-                monkeypatch.setenv("ICPMI_PREP_KNN", mode)
+                libopt.setenv("ICPMI_PREP_KNN", mode)
                 got[mode] = uicp.estimate_normals_2d(pts, k)
             assert np.array_equal(got["grid"], got["sweep"]), (len(pts), k)
             no = oracle.normals_2d(pts, k)
@@ -155,7 +155,7 @@ def test_normals_grid_and_sweep_searches_agree(uicp, monkeypatch):
                 assert ok.mean() >= 0.99, (len(pts), k, ok.mean())
             else:
                 assert ok.mean() > 0.5 or len(pts) <= 7 or pts is lattice, (len(pts), k, ok.mean())
-    monkeypatch.delenv("ICPMI_PREP_KNN")
+    libopt.delenv("ICPMI_PREP_KNN")
 
 
 def test_normals_and_icp_with_more_than_31_neighbours(uicp):
@@ -177,7 +177,7 @@ def test_normals_and_icp_with_more_than_31_neighbours(uicp):
     assert uicp.last_icp_info["iterations"] == io["iters"] and rot_err(R, t, Ro, to) < FRO_TOL
 
 
-def test_bearing_order_gives_identical_results(uicp, monkeypatch):
+def test_bearing_order_gives_identical_results(uicp, libopt):
     """A prepared target may be sorted along a projection or by bearing about the frame origin (sweep.hpp, SWEEP_POLAR);
     the library picks per cloud by estimated window size.  The order only changes how fast the exact searches run:
     forcing either (ICPMI_POLAR=0 / 2) must give the same normals and the same registrations bit for bit — also where
@@ -198,9 +198,9 @@ def test_bearing_order_gives_identical_results(uicp, monkeypatch):
         got = {}
         for mode in ("0", "2", None):
             if mode is None:
-                monkeypatch.delenv("ICPMI_POLAR", raising=False)
+                libopt.delenv("ICPMI_POLAR", raising=False)
             else:
-                monkeypatch.setenv("ICPMI_POLAR", mode)
+                libopt.setenv("ICPMI_POLAR", mode)
             b = batch.IcpBatch([p[0] for p in pairs] + [p[1] for p in pairs], np.arange(len(pairs)),
                                np.arange(len(pairs), 2 * len(pairs)), 1e-10, 60, 0.04, method=method, **extra)
             got[mode] = b.run().cpu().numpy().copy()
@@ -210,12 +210,12 @@ def test_bearing_order_gives_identical_results(uicp, monkeypatch):
     for pts in (tgts[0], tgts[0] + far, rng.uniform(-2, 2, (1100, 2)), lattice, seam):
         nrm = {}
         for mode in ("0", "2"):
-            monkeypatch.setenv("ICPMI_POLAR", mode)
-            monkeypatch.setenv("ICPMI_PREP_KNN", "sweep")
+            libopt.setenv("ICPMI_POLAR", mode)
+            libopt.setenv("ICPMI_PREP_KNN", "sweep")
             nrm[mode] = uicp.estimate_normals_2d(pts, 12)
         assert np.array_equal(nrm["0"], nrm["2"]), len(pts)
-    monkeypatch.delenv("ICPMI_POLAR")
-    monkeypatch.delenv("ICPMI_PREP_KNN")
+    libopt.delenv("ICPMI_POLAR")
+    libopt.delenv("ICPMI_PREP_KNN")
 
 
 def test_p2l_solve(uicp):
@@ -314,10 +314,10 @@ GRID_KW = dict(resolution=0.05, p_hit=0.85, p_miss=0.42, log_odds_min=-8.0, log_
 
 
 @pytest.fixture(params=["tiles", "atomic"])
-def raypath(request, monkeypatch):
+def raypath(request, libopt):
     """Both counting passes of the ray-cast: per tile in LDS (the default for a replay of several scans whose box the
     caller knows) and integer atomics per (beam, cell) on the scan's counter grid (single scans, callers without a box)."""
-    monkeypatch.setenv("ICPMI_RAYCAST", request.param)      # "tiles" also sends single scans down the tile pass
+    libopt.setenv("ICPMI_RAYCAST", request.param)      # "tiles" also sends single scans down the tile pass
     return request.param
 
 
@@ -1022,7 +1022,7 @@ def test_large_batch_with_wide_clouds_takes_the_second_launch(uicp):
         assert int(res[i, 14]) == io["iters"] and rot_err(res[i, :4].reshape(2, 2), res[i, 9:11], Ro, to) < FRO_TOL
 
 
-def test_two_stage_run_of_a_large_batch_is_the_single_launch_bit_for_bit(uicp, monkeypatch):
+def test_two_stage_run_of_a_large_batch_is_the_single_launch_bit_for_bit(uicp, libopt):
     """A batch of >= 1 024 pairs runs the fused ICP kernel in two stages: everybody up to 12 iterations, then the pairs
     still running — parked with their moving rows, matches and totals — together in a second launch (so that the
     150-iteration pairs do not finish alone at the end of one long launch).  The continuation searches afresh, finds
@@ -1040,7 +1040,7 @@ def test_two_stage_run_of_a_large_batch_is_the_single_launch_bit_for_bit(uicp, m
     for case in cases:
         out = {}
         for stages in ("1", "2"):
-            monkeypatch.setenv("ICPMI_ICP2_STAGES", stages)
+            libopt.setenv("ICPMI_ICP2_STAGES", stages)
             kw = dict(error_threshold=1e-10, max_iterations=case["max_iterations"], voxel_size=0.04, method=case["method"],
                       normal_k=12, max_corr_dist=case["max_corr_dist"])
             if case["init"] is not None:
@@ -1132,3 +1132,114 @@ def test_pose_graph_python_index_semantics(uicp):
     a, ea = build(8)
     b, eb = build(-1)
     assert np.array_equal(a, b) and ea == eb
+
+
+def test_mixed_batch_of_scans_and_one_large_target(uicp):
+    """One batch that holds ordinary scan targets (~1 400 rows) AND a target above 4 096 rows (a rolling submap).  The
+    fused launch then searches every target in place (one instantiation per batch), which cannot walk a bearing order:
+    the prepare step must sort such a batch along projections only (it used to pick the bearing order for the scans,
+    whose pairs then came back ICPMI_ST_EMPTY with R = I and err = inf and no error code)."""
+    from icpmi import batch, synth
+    srcs, tgts = synth.loop_closure_batch(6, seed0=7300)
+    segs = synth.maze_segments()
+    poses = synth.trajectory(12)
+    big = np.vstack([synth.to_world(synth.scan(p, 900 + i, segs=segs), p) for i, p in enumerate(poses)])   # 24 576 rows
+    cur = synth.scan(poses[6], 977, segs=segs)
+    th = np.deg2rad(1.0)
+    R0 = np.array([[np.cos(poses[6][2] + th), -np.sin(poses[6][2] + th)], [np.sin(poses[6][2] + th), np.cos(poses[6][2] + th)]])
+    t0 = np.array(poses[6][:2]) + [0.05, -0.04]
+    clouds = srcs + [cur] + tgts + [big]
+    B = 7
+    Ri = np.stack([np.eye(2)] * 6 + [R0])
+    ti = np.stack([np.zeros(2)] * 6 + [t0])
+    for method, extra in (("point_to_line", dict(normal_k=12)), ("point_to_point", dict(max_corr_dist=1.5))):
+        b = batch.IcpBatch(clouds, np.arange(B), np.arange(B, 2 * B), 1e-10, 40, 0.04, R_init=Ri, t_init=ti, method=method, **extra)
+        res = b.run().cpu().numpy()
+        cnt = b.vox.cnt.cpu().numpy()
+        assert cnt[2 * B - 1] > 4096 and cnt[B:2 * B - 1].max() <= 2048
+        assert (res[:, 15] != 4).all(), res[:, 15]                         # nobody is ICPMI_ST_EMPTY
+        for i in range(B):
+            Ro, to, eo, io = oracle.icp(clouds[i], clouds[B + i], 1e-10, 40, 0.04, R_init=Ri[i], t_init=ti[i], method=method, **extra)
+            assert int(res[i, 14]) == io["iters"], (method, i)
+            assert rot_err(res[i, :4].reshape(2, 2), res[i, 9:11], Ro, to) < FRO_TOL, (method, i)
+
+
+def test_pair_context_keeps_the_sweep_path_above_4096_rows_in_all(uicp):
+    """ICP() on a 2 100-row scan against a 3 000-row target: 5 100 rows in all, each cloud within the on-chip limit —
+    the pair context must stay on the sorted-sweep kernels (it used to fall back on the exhaustive kernel for good)."""
+    from icpmi import batch, synth
+    rng = np.random.default_rng(5)
+    segs = synth.maze_segments()
+    a = np.vstack([synth.scan((0.0, 0.0, 0.0), 31, segs=segs), rng.uniform(-3, 3, (52, 2))])
+    bb = np.vstack([synth.scan((0.1, -0.05, np.deg2rad(2.0)), 32, segs=segs), rng.uniform(-3, 3, (952, 2))])
+    assert len(a) == 2100 and len(bb) == 3000
+    R, t, err = uicp.ICP(a, bb, 1e-10, 60, 0.005, method="point_to_line", normal_k=40)     # k > 31: the fast path only
+    ctx = batch.PairContext.get()
+    assert ctx.batch.fast and ctx.cap_s <= batch.PREP_MAX_POINTS and ctx.cap_t <= batch.PREP_MAX_POINTS
+    Ro, to, eo, io = oracle.icp(a, bb, 1e-10, 60, 0.005, method="point_to_line", normal_k=40)
+    assert uicp.last_icp_info["iterations"] == io["iters"] and rot_err(R, t, Ro, to) < FRO_TOL
+
+
+def test_library_options_and_shutdown(uicp):
+    """icpmi_set_option / icpmi_shutdown (include/icpmi.h, "library state"): unknown names are refused, a set option
+    takes effect without touching the environment, shutdown destroys the side streams and later calls make them again."""
+    from icpmi import _lib, batch, synth
+    with pytest.raises(_lib.IcpmiError):
+        _lib.set_option("NO_SUCH_SWITCH", "1")
+    srcs, tgts = synth.loop_closure_batch(4, seed0=100)
+    kw = dict(error_threshold=1e-10, max_iterations=30, voxel_size=0.04, method="point_to_line", normal_k=12)
+    out = {}
+    for mode in ("0", None):
+        _lib.set_option("ICPMI_POLAR", mode)
+        b = batch.IcpBatch(srcs + tgts, np.arange(4), np.arange(4, 8), **kw)
+        out[mode] = b.run().cpu().numpy().copy()
+        dirs = b.prepared[b.raw.total_rows * 40: b.raw.total_rows * 40 + 8 * 4].view(torch_int32()).cpu().numpy()
+        assert (dirs[4:] == 4).any() == (mode is None), (mode, dirs)        # bearing order only when allowed
+    assert np.array_equal(out["0"], out[None])
+    _lib.shutdown()
+    b = batch.IcpBatch(srcs + tgts, np.arange(4), np.arange(4, 8), **kw)
+    assert np.array_equal(b.run().cpu().numpy(), out[None])
+    _lib.shutdown()
+
+
+def torch_int32():
+    import torch
+    return torch.int32
+
+
+def test_rccl_world_of_one_gathers_results_and_bands(uicp):
+    """The `nccl` backend of torch.distributed IS RCCL on ROCm.  A one-GPU box cannot run the 8-rank job, but a world of
+    one still initialises RCCL, creates the communicator on the device and pushes both collectives of icpmi.dist
+    (result records, row bands) through ncclAllGather on device tensors."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from icpmi import dist as idist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+    try:
+        assert dist.get_backend() == "nccl"
+        rng = np.random.default_rng(3)
+        local = torch.from_numpy(rng.normal(size=(37, 16))).to(dev)
+        got = idist.gather_results(local, 37, 0, 1, force_collective=True)
+        assert got.is_cuda and torch.equal(got, local)
+        band = torch.from_numpy(rng.normal(size=(50, 64)).astype(np.float32)).to(dev)
+        full = idist.gather_bands(band, [0, 50], 0, 1, force_collective=True)
+        assert full.is_cuda and torch.equal(full, band)
+        # the sharded batch end to end on the one rank (pairs -> IcpBatch -> all_gather)
+        from icpmi import synth
+        srcs, tgts = synth.loop_closure_batch(5, seed0=900)
+        res = idist.icp_batch_sharded(srcs, tgts, 1e-10, 30, 0.04, method="point_to_line", normal_k=12)
+        for i in (0, 4):
+            Ro, to, eo, io = oracle.icp(srcs[i], tgts[i], 1e-10, 30, 0.04, method="point_to_line", normal_k=12)
+            r = res[i].cpu().numpy()
+            assert int(r[14]) == io["iters"] and rot_err(r[:4].reshape(2, 2), r[9:11], Ro, to) < FRO_TOL
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
