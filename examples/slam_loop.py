@@ -11,15 +11,17 @@ end to end on a synthetic drive:
     submap:         RollingSubmap.attempt_icp: rotation search about the  slam.py:111-225, 505-536
                     predicted pose (narrow about the IMU yaw) + p2p ICP
     mapping:        OccupancyGrid2D.update_scan                           slam.py:552-557
-    loop closure:   every candidate is pre-aligned (rotation_search) and   slam.py:566-620
-                    registered — all candidates in ONE batch — and, as in
+    loop closure:   every candidate goes through _run_icp_pair (rotation    slam.py:566-620, 53-98
+                    search, then ICP from its result) — all candidates in
+                    ONE batch, nothing returning to the host between the
+                    search and the ICP (icpmi.prealign) — and, as in
                     the reference, the FIRST candidate in order whose error
                     is below the gate is accepted: it adds a pose-graph
                     edge, the graph is optimised, poses are rewritten, the
                     submap buffer and the occupancy grid are rebuilt
                     (replay of all scans)
 
-The geometry behind the loop is a `backend` (rotation_search, ICP, icp_batch, Submap, Grid, Graph): the MI355X
+The geometry behind the loop is a `backend` (rotation_search, ICP, run_icp_pairs, Submap, Grid, Graph): the MI355X
 drop-ins by default; the tests inject the CPU oracle there to check the whole composition scan by scan.
 
 It also writes and re-reads the drive in the reference's wire formats: lidar lines
@@ -37,7 +39,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "iterative-closest-point-avmi_amd"))
 
-from icpmi import batch, synth  # noqa: E402
+from icpmi import batch, prealign, synth  # noqa: E402
 from icpmi.submap import RollingSubmap  # noqa: E402
 from utilities import features  # noqa: E402
 from utilities import icp as uicp  # noqa: E402
@@ -115,9 +117,10 @@ class GpuBackend:
     Graph = PoseGraph2D
 
     @staticmethod
-    def icp_batch(source, targets, R_init, t_init, **kw):
-        """-> (R [B,2,2], t [B,2], err [B], iterations [B]): the current scan against every candidate, one launch chain."""
-        R, t, err, info = batch.icp_batch(source, targets, R_init=R_init, t_init=t_init, **kw)
+    def run_icp_pairs(source, targets, feat_cfg, icp_cfg):
+        """_run_icp_pair(source, target) for every candidate (slam.py:575-579 -> 53-98) -> (R [B,2,2], t [B,2], err [B],
+        iterations [B]): rotation searches and ICPs of all candidates as one chain of launches."""
+        R, t, err, info = prealign.run_icp_pair_batch(source, targets, icp_cfg, feat_cfg)
         return R, t, err, info["iters"]
 
 
@@ -189,16 +192,14 @@ def run(n_scans=60, log_path=None, verbose=True, imu_path=None, loop=False, use_
             odo_err = err if err <= 0.15 else 0.15
             graph.add_edge(node - 1, node, relative_transform_vec(history[-2][1], pose), np.eye(3) / max(odo_err, 1e-6))
         # loop closure candidates: old scans near the current position (slam.py:230-268), tried in order; each is
-        # pre-aligned and registered as _run_icp_pair does (slam.py:53-98) — all of them in one batch — and the FIRST
-        # whose error is below the gate wins (slam.py:582-597)
+        # pre-aligned and registered as _run_icp_pair does (slam.py:53-98) — all of them in one batch, searches and ICPs
+        # chained on the device — and the FIRST whose error is below the gate wins (slam.py:582-597)
         t0 = time.perf_counter()
         if i >= 30 and i % 10 == 0:
             cands = [k for k, (_, pk) in enumerate(history[:-20]) if np.linalg.norm(pk[:2, 2] - pose[:2, 2]) < 3.0][:max_candidates]
             if cands:
-                pre = [be.rotation_search(cur, history[k][0], voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
-                       for k in cands]
-                R, t, err, its = be.icp_batch(cur, [history[k][0] for k in cands], np.array([p[0] for p in pre]),
-                                              np.array([p[1] for p in pre]), **icp_kw)
+                R, t, err, its = be.run_icp_pairs(cur, [history[k][0] for k in cands],
+                                                  dict(rotation_voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1), icp_kw)
                 ok = np.flatnonzero(np.asarray(err) < lc_error_threshold)
                 first = int(ok[0]) if len(ok) else -1
                 shown = first if first >= 0 else int(np.argmin(err))

@@ -237,6 +237,36 @@ int icpmi_rotation_search(const double* pts, int32_t n_src, int32_t n_tgt, doubl
                           int32_t centred, double shift_x, double shift_y,
                           double* out_record, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- batched pre-alignment: rotation_search (utilities/features.py:165-242) for every pair of a batch — the first
+ * half of _run_icp_pair (slam.py:53-98), which slam.py:575-579 calls once per loop-closure candidate ----------------
+ * pts / off_dev / off_host: a cloud set of RAW 2-D clouds (at most 4096 rows each); pair b searches the rotation of
+ * cloud pair_src[b] onto cloud pair_tgt[b].  tgt_ids (device, optional): the distinct target clouds (only they are
+ * put in search order; NULL = every cloud).  One chain of launches: voxel filter of every cloud at voxel_size, the
+ * means of the filtered clouds, the search order of the targets, then ONE workgroup per pair for both sweeps.  Angle
+ * grids as in icpmi_rotation_search (coarse_cs; fine_cs / fine_cnt / max_fine: one fine grid per coarse winner; the
+ * caller's NumPy cos / sin; at most 1024 coarse angles and 1024 per fine grid).
+ * Only the arg-min of the coarse scores matters to the reference (features.py:223), so a workgroup bounds every
+ * coarse score from below with a distance field of its target (one look-up per row), scores angles exactly — same
+ * float64 nearest-neighbour distances as icpmi_rotation_search — in order of that bound, and stops at the first angle
+ * whose bound exceeds the best exact score: np.argmin over the scored angles (first minimum) is np.argmin over all.
+ * out_records [n_pairs][16]: slots 0..10 as icpmi_rotation_search's record (filtered counts, mean of the source (2),
+ * mean of the target (2), winning coarse index, its score, length of its fine grid, winning fine index, its score);
+ * 11 status — 0 searched; 1 a filtered cloud has fewer than 5 points (features.py:203-204: identity, zeros, inf);
+ * 2 a filtered cloud exceeds the on-chip capacity (not searched: use icpmi_rotation_search); 3 the winner's fine grid
+ * is empty (np.argmin raises in the reference); 12, 13 coarse / fine angles scored exactly (diagnostic).
+ * out_init (optional) [n_pairs][6]: R row-major then t = mu_t - R mu_s (features.py:235-237) — the `init` argument of
+ * icpmi_icp_batch, so pre-alignment and ICP chain on one stream with no host round trip; identity for status != 0.
+ * max_rows_hint: an upper bound the caller expects for the FILTERED clouds (0: none).  The on-chip copies are sized
+ * by min(largest raw cloud, 2048, hint); up to 1024 rows two workgroups share a CU.  A pair beyond it gets status 2. */
+size_t icpmi_rotation_search_batch_workspace_bytes(int32_t total_rows, int32_t n_clouds, int32_t max_n);
+int icpmi_rotation_search_batch(const double* pts, const int32_t* off_dev, const int32_t* off_host, int32_t n_clouds,
+                                const int32_t* tgt_ids, int32_t n_tgt_ids,
+                                const int32_t* pair_src, const int32_t* pair_tgt, int32_t n_pairs,
+                                double voxel_size, const double* coarse_cs, int32_t n_coarse,
+                                const double* fine_cs, const int32_t* fine_cnt, int32_t max_fine,
+                                int32_t max_rows_hint, double* out_records, double* out_init,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- OccupancyGrid2D, utilities/mapping.py ---------------------------------
  * world -> cell index, mapping.py:57-60,94-98: floor((w - min) / res), float64
  * IEEE division, result as int64. */

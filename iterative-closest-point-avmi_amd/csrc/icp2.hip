@@ -224,6 +224,8 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
     double2* lds_nrm = reinterpret_cast<double2*>(dyn + (size_t)a.lds_points * 16);
     int32_t* lds_orig = reinterpret_cast<int32_t*>(dyn + (size_t)a.lds_points * 32);      // !FILT: row map (4 B per point)
     float4* lds_sq = reinterpret_cast<float4*>(dyn + (size_t)a.lds_points * 32) + 1;     //  FILT: float32 images (16 B per point), one padding entry at either end
+    // (no block boxes here: the far scan of sweep.hpp costs this kernel 11 registers — spills at six waves per SIMD — and
+    // 35 % of its time on pairs that start close, to halve the time of pairs that start metres away; measured, round 3)
     const double2* sxy = TGT_LDS ? lds_xy : a.g_sxy + a.off[tc];
     const double2* snrm = TGT_LDS ? lds_nrm : a.g_snrm + a.off[tc];
     const int32_t* sorig = TGT_LDS ? lds_orig : a.g_sorig + a.off[tc];
@@ -283,18 +285,19 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 rmax = fmaxf(rmax, fmaxf(fabsf(q.x), fabsf(q.y)));
             }
             if (tid == 0) { lds_sq[-1] = make_float4(0.f, 0.f, 0.f, 0.f); lds_sq[M] = make_float4(0.f, 0.f, 0.f, 0.f); }
-            __syncthreads();                                     // rt_bits = 0 is visible
+            __syncthreads();                                     // rt_bits = 0 is visible, the images are complete
             atomicMax(&rt_bits, __float_as_int(rmax));           // non-negative floats order like their bits
         }
         // moving source rows in registers: row n = s*THREADS + tid
         double px[ICP2_SMAX], py[ICP2_SMAX];
         int pos[ICP2_SMAX];
         // Movement budget of each row's match.  A search returns the two nearest
-        // target points and the distance d3 of the third.  While the row is
-        // displaced from where it was searched (the anchor) by less than
-        // (d3 - d1)/2, every other target point is still farther than the nearer
-        // of those two (triangle inequality), so the match is the better of the
-        // two — two distance evaluations instead of a search.  Exact: margins cover
+        // target points and the distance d3 of the third.  While the row's
+        // displacement from where it was searched (the anchor) plus its current
+        // distance to the nearer of those two stays below d3, every other target
+        // point is still farther (triangle inequality), so the match is the better
+        // of the two — two distance evaluations instead of a search.  `budget` holds
+        // d3 (rounded down).  Exact: margins cover
         // rounding, equal distances fall back on the row rule or on a new search.
         // Net displacement, so a pair that oscillates in a limit cycle (the usual
         // reason for running to max_iterations) stops searching too.
@@ -366,21 +369,31 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
 #pragma unroll
             for (int s = 0; s < ICP2_SMAX; ++s) {
                 const bool valid = s < S && s * THREADS + tid < N;
-                // |dx| + |dy| >= the distance between the row and its anchor
-                const bool within = valid && (fabs(px[s] - (double)ax[s]) + fabs(py[s] - (double)ay[s])) * 1.000000001 < (double)budget[s];
+                // The two kept candidates' distances first (nearly every row needs them anyway), then the test with the
+                // CURRENT distance dq to the better of the two: every other target point was at least d3 from the anchor,
+                // so it is at least d3 - delta from the row now (delta: the row's displacement since its search,
+                // |dx| + |dy| >= it), and the better kept candidate is THE nearest neighbour while dq < d3 - delta.
+                // (Round 2 tested delta < (d3 - d1) / 2, which implies this — dq <= d1 + delta — and is about half as
+                // generous: rows of a limit cycle slide along their wall, where dq hardly grows.)
+                const int pa = max(pos[s], 0), pb = pos2[s] >= 0 ? pos2[s] : pa;
+                const double2 c = sxy[pa], e = sxy[pb];
+                const double dx = px[s] - c.x, dy = py[s] - c.y;
+                const double ex = px[s] - e.x, ey = py[s] - e.y;
+                double q2 = 0.0, w2 = 0.0;
+                q2 += dx * dx;
+                q2 += dy * dy;
+                w2 += ex * ex;
+                w2 += ey * ey;
+                // upper bound of dq in single precision: (float) rounds within 2^-24, v_sqrt_f32 within an ulp
+                const float dq_up = __builtin_amdgcn_sqrtf((float)fmin(q2, w2)) * 1.000001f + 1e-30f;
+                const bool within = valid && (fabs(px[s] - (double)ax[s]) + fabs(py[s] - (double)ay[s])) * 1.000000001 + (double)dq_up < (double)budget[s];
                 srch[s] = valid && !within;
+#ifdef ICP2_X_NOSEARCH_FROM          // experiment: an upper bound on what the late searches cost (WRONG results)
+                if (it >= ICP2_X_NOSEARCH_FROM && pos[s] >= 0) srch[s] = false;
+#endif
                 if (within) {
                     // straight-line: a missing second candidate stands in as the first (never better), and only an
                     // exact tie of the two distances takes a branch (to compare the rows)
-                    const int pa = pos[s], pb = pos2[s] >= 0 ? pos2[s] : pos[s];
-                    const double2 c = sxy[pa], e = sxy[pb];
-                    const double dx = px[s] - c.x, dy = py[s] - c.y;
-                    const double ex = px[s] - e.x, ey = py[s] - e.y;
-                    double q2 = 0.0, w2 = 0.0;
-                    q2 += dx * dx;
-                    q2 += dy * dy;
-                    w2 += ex * ex;
-                    w2 += ey * ey;
                     bool second_wins = w2 < q2;
                     if (w2 == q2 && pb != pa) {
                         if constexpr (FILT) second_wins = sweepf_row(lds_sq[pb]) < sweepf_row(lds_sq[pa]);
@@ -390,7 +403,8 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                     pos2[s] = pos2[s] >= 0 ? (second_wins ? pa : pb) : -1;
                 }
             }
-            if (it < ICP2_PLAIN_ITERS) {
+            // (a continuation starts at iteration STAGE1_ITERATIONS > ICP2_PLAIN_ITERS: its instantiation holds the top-two search only)
+            if (!RESUME && it < ICP2_PLAIN_ITERS) {
                 // the first steps move every row by more than any budget: plain 1-NN (smallest window), started at
                 // the row's own projection — the previous match only seeds the bound (it lies a whole step away)
 #pragma unroll
@@ -401,7 +415,7 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                         else pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], it < ICP2_PLAIN_CENTRED, d2s);
                     }
             } else {
-                const bool centred = it < ICP2_CENTRED_ITERS;
+                const bool centred = !RESUME && it < ICP2_CENTRED_ITERS;
 #pragma unroll
                 for (int s = 0; s < ICP2_SMAX; ++s)
                     if (srch[s]) {
@@ -409,9 +423,9 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                         if constexpr (FILT) t2 = sweepf_top2(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], centred);
                         else t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], centred);
                         pos[s] = t2.p1; pos2[s] = t2.p2;
-                        const double d1 = sqrt(t2.s1), d3 = sqrt(t2.s3);
-                        // minus the rounding of the single-precision anchor; rounded down
-                        const double bud = (d3 - d1) * 0.4999999995 - 1e-13 * (d3 + d1) - 1.3e-7 * (fabs(px[s]) + fabs(py[s]));
+                        const double d3 = sqrt(t2.s3);
+                        // the third distance, minus the rounding of the single-precision anchor; rounded down
+                        const double bud = d3 - 1e-13 * d3 - 1.3e-7 * (fabs(px[s]) + fabs(py[s]));
                         float bf = (float)bud;
                         bf = bf - fabsf(bf) * 1e-6f;
                         budget[s] = t2.s3 < __builtin_inf() ? bf : __builtin_inff();
@@ -630,11 +644,21 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_wide_ker
     }
 }
 
-// second stage of a two-stage run: the workgroups walk the list of parked pairs
+// second stage of a two-stage run: workgroup j continues the j-th parked pair.  No loop over the list here: with one the
+// 768 x 2 shape needs 93 registers instead of 79 and spills 56 B per lane at its budget of 80 (six waves per SIMD); the
+// launcher starts an eighth of the batch's pairs as workgroups (about one pair in twelve is parked; a workgroup beyond the
+// list leaves at once) and ...
 template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT>
 __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_resume_kernel(Icp2Args a) {
+    if ((int)blockIdx.x >= *a.list_count) return;
+    icp2_pair<THREADS, ICP2_SMAX, TGT_LDS, FILT, true>(a, __builtin_amdgcn_readfirstlane(a.list[blockIdx.x]));
+}
+
+// ... the parked pairs beyond that (none, usually) are walked by the few workgroups of this one
+template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT>
+__global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_resume_rest_kernel(Icp2Args a, int first) {
     const int count = *a.list_count;
-    for (int j = blockIdx.x; j < count; j += gridDim.x) {
+    for (int j = first + blockIdx.x; j < count; j += gridDim.x) {
         // the pair index in a scalar register: everything addressed through it stays scalar
         icp2_pair<THREADS, ICP2_SMAX, TGT_LDS, FILT, true>(a, __builtin_amdgcn_readfirstlane(a.list[j]));
         __syncthreads();                                    // LDS is staged again for the next pair
@@ -697,6 +721,11 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
             if (hipFuncSetAttribute((const void*)icp2_resume_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                     (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                               \
             icp2_resume_kernel<TT, SS, L, F><<<stage2_grid, TT, lds, st>>>(c);                                                   \
+            if (stage2_grid < n_pairs) {                    /* more parked pairs than workgroups: the rest of the list */         \
+                if (hipFuncSetAttribute((const void*)icp2_resume_rest_kernel<TT, SS, L, F>,                                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP; \
+                icp2_resume_rest_kernel<TT, SS, L, F><<<256, TT, lds, st>>>(c, stage2_grid);                                     \
+            }                                                                                                                    \
         }                                                                                                                        \
     } while (0)
     a.n_lo = -1; a.m_lo = 0; a.skip_over = 0;
@@ -731,9 +760,9 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     const bool have_ws = workspace && workspace_bytes >= st_bytes;
     const bool two_stage = many && have_ws && p->max_iterations >= 2 * STAGE1_ITERATIONS &&
                            !(senv && senv[0] == '1') && (p->method == ICPMI_POINT_TO_LINE || (senv && senv[0] == '2'));
-    // second-stage workgroups: a sixteenth of the pairs (about one pair in thirteen is parked; measured 5.37 / 5.25 /
-    // 5.51 ms at an eighth / a sixteenth / a thirty-second of 16 384 pairs), each walking the list
-    const int stage2_grid = n_pairs / 16 > 256 ? n_pairs / 16 : 256;
+    // second-stage workgroups: an eighth of the pairs, one parked pair each (about one pair in twelve is parked; the others
+    // leave at once), then 256 workgroups that walk whatever the list holds beyond that
+    const int stage2_grid = n_pairs / 8 > 256 ? n_pairs / 8 : 256;
     // the launch for wide clouds: a thirty-second (a launch of 4 096 workgroups that find an empty list still takes 100 us)
     const int wide_grid = n_pairs < 256 ? n_pairs : (n_pairs / 32 > 256 ? n_pairs / 32 : 256);
     if (have_ws && (two_stage || T2)) {

@@ -542,10 +542,103 @@ struct SweepFRound {
     }
 };
 
+// ── far queries: boxes of blocks of the sort order ───────────────────────────────────────────────────
+// A walk visits every point whose key lies within the bound of the query's key: a query that is metres from every
+// target point (a pair started from a wrong pre-alignment, a rotation far from the right one) walks most of the
+// cloud — ~1 400 candidates instead of ~10 — and a wave waits for its longest lane.  So a walk that has taken
+// SWEEP_FAR_ROUNDS rounds gives up and the search is finished by a scan over BLOCKS of SWEEP_BLOCK consecutive sorted
+// positions, each with the bounding box of its float32 images (sbox[b] = min x, min y, max x, max y): a block whose box
+// is farther than the bound is skipped whole, the points of the others go through the same float32 filter and exact
+// test as in the walk.  In bearing order a block is a contiguous piece of wall (tight boxes: ~100 box tests and two or
+// three blocks of points per query); along a projection the boxes are loose and the scan degrades to the filter over
+// the points — never worse than the walk it replaces.  Exact: the box distance is computed with the very operations of
+// the point filter (monotone roundings), so it never exceeds the filter value of a point inside the box.
+constexpr int SWEEP_BLOCK = 16;
+#ifndef SWEEP_FAR_ROUNDS
+#define SWEEP_FAR_ROUNDS 24
+#endif
+
+// boxes of the blocks of m staged images (all threads of the workgroup; the images must be complete: barrier before)
+__device__ __forceinline__ void sweepf_build_boxes(const float4* sq, int m, float4* sbox, int tid, int nthreads) {
+    for (int b = tid; b * SWEEP_BLOCK < m; b += nthreads) {
+        const int i1 = min(m, (b + 1) * SWEEP_BLOCK);
+        float x0 = __builtin_inff(), y0 = __builtin_inff(), x1 = -__builtin_inff(), y1 = -__builtin_inff();
+        for (int i = b * SWEEP_BLOCK; i < i1; ++i) {
+            const float4 c = sq[i];
+            x0 = fminf(x0, c.x); y0 = fminf(y0, c.y); x1 = fmaxf(x1, c.x); y1 = fmaxf(y1, c.y);
+        }
+        sbox[b] = make_float4(x0, y0, x1, y1);
+    }
+}
+
+// float32 lower bound of the filter value (SweepFRound: fma(dx, dx, dy * dy)) of any image inside the box
+__device__ __forceinline__ float sweepf_box_s2(const float4 bb, float qx, float qy) {
+    const float dx = fmaxf(fmaxf(bb.x - qx, qx - bb.z), 0.0f), dy = fmaxf(fmaxf(bb.y - qy, qy - bb.w), 0.0f);
+    return __builtin_fmaf(dx, dx, dy * dy);
+}
+
+// finish a 1-NN search over all blocks (best / bpos: what the walk has found so far)
+__device__ __forceinline__ void sweepf_far_nn(const float4* sq, const double2* sxy, const float4* sbox, const SweepFQuery& fq, int m,
+                                              double qx, double qy, double& best, int& bpos, float& T) {
+    float W;
+    for (int b = 0; b * SWEEP_BLOCK < m; ++b) {
+        if (sweepf_box_s2(sbox[b], fq.x, fq.y) > T) continue;          // NaN compares false: the block is scanned
+        const int i1 = min(m, (b + 1) * SWEEP_BLOCK);
+        for (int i = b * SWEEP_BLOCK; i < i1; ++i) {
+            const float4 c = sq[i];
+            const float ex = fq.x - c.x, ey = fq.y - c.y;
+            if (__builtin_fmaf(ex, ex, ey * ey) > T) continue;
+            const double s = sweep_d2(qx, qy, sxy[i]);
+            if (s == best && i != bpos) {                              // exact tie: the lowest original row wins
+                if (sweepf_row(c) < sweepf_row(sq[bpos])) bpos = i;
+            }
+            if (s < best) { best = s; bpos = i; fq.bounds(best, W, T); }
+        }
+    }
+}
+
+// one exact candidate into a top-two list (the rule everywhere: (squared distance, original row) ascending)
+__device__ __forceinline__ void top2_insert(Top2& t, double s, int i, int row, const float4* sq) {
+    if (s == t.s1 || s == t.s2) {
+        const int r1 = sweepf_row(sq[t.p1]);
+        const int r2 = t.p2 >= 0 ? sweepf_row(sq[t.p2]) : 0x7fffffff;
+        if (s < t.s1 || (s == t.s1 && row < r1)) { t.s3 = t.s2; t.s2 = t.s1; t.p2 = t.p1; t.s1 = s; t.p1 = i; }
+        else if (s < t.s2 || row < r2) { t.s3 = t.s2; t.s2 = s; t.p2 = i; }
+        else t.s3 = s;                                                 // tie with the second, lost on the row
+    } else {
+        const bool c1 = s < t.s1, c2 = s < t.s2, c3 = s < t.s3;
+        t.s3 = c2 ? t.s2 : (c3 ? s : t.s3);
+        t.s2 = c1 ? t.s1 : (c2 ? s : t.s2);
+        t.p2 = c1 ? t.p1 : (c2 ? i : t.p2);
+        t.s1 = c1 ? s : t.s1;
+        t.p1 = c1 ? i : t.p1;
+    }
+}
+
+// finish a top-two search over all blocks.  The list holds positions only for its first two entries: a point met again
+// that is one of them is skipped; one that gave the third distance (or lost earlier) compares equal or worse and changes
+// nothing.  Entries of the list the walk had filled from candidates it met before giving up are therefore kept.
+__device__ __forceinline__ void sweepf_far_top2(const float4* sq, const double2* sxy, const float4* sbox, const SweepFQuery& fq, int m,
+                                                double qx, double qy, Top2& t, float& T) {
+    float W;
+    for (int b = 0; b * SWEEP_BLOCK < m; ++b) {
+        if (sweepf_box_s2(sbox[b], fq.x, fq.y) > T) continue;
+        const int i1 = min(m, (b + 1) * SWEEP_BLOCK);
+        for (int i = b * SWEEP_BLOCK; i < i1; ++i) {
+            const float4 c = sq[i];
+            const float ex = fq.x - c.x, ey = fq.y - c.y;
+            if (__builtin_fmaf(ex, ex, ey * ey) > T || i == t.p1 || i == t.p2) continue;
+            const double s = sweep_d2(qx, qy, sxy[i]);
+            top2_insert(t, s, i, sweepf_row(c), sq);
+            fq.bounds(t.s3, W, T);
+        }
+    }
+}
+
 // sweep_nn with the filter: sq = float32 images (padded by one entry at either end), sxy = exact points (read only
-// for candidates that pass)
+// for candidates that pass); sbox (optional) = block boxes for queries far from the cloud
 __device__ __forceinline__ int sweepf_nn(const float4* sq, const double2* sxy, const SweepF& f, int m, int dir, double uabs,
-                                         double qx, double qy, int seed, bool CENTRED, double& d2_out) {
+                                         double qx, double qy, int seed, bool CENTRED, double& d2_out, const float4* sbox = nullptr) {
     const SweepFQuery fq(f, dir, uabs, qx, qy);
     double best = __builtin_inf();
     float W = __builtin_inff(), T = __builtin_inff();
@@ -559,9 +652,12 @@ __device__ __forceinline__ int sweepf_nn(const float4* sq, const double2* sxy, c
     const bool from_seed = seeded && !CENTRED && !(fq.polar && fabsf(sq[seed].z - fq.u) > 3.0f);
     const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
     SweepFWalk w(from_seed ? seed - 1 : h0 - 1, h0, m, fq.u);
+    int rounds = 0;
+    bool far = false;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         while (w.more()) {
+            if (sbox && ++rounds > SWEEP_FAR_ROUNDS) { far = true; break; }
             const SweepFRound r(sq, w, fq, W, T);
             if (r.pr || r.pl) {                                        // might win (or tie): the exact test
 #pragma unroll
@@ -579,15 +675,16 @@ __device__ __forceinline__ int sweepf_nn(const float4* sq, const double2* sxy, c
             }
             r.advance(w);
         }
-        if (!fq.polar || !w.wrap(m)) break;
+        if (far || !fq.polar || !w.wrap(m)) break;
     }
+    if (far) sweepf_far_nn(sq, sxy, sbox, fq, m, qx, qy, best, bpos, T);
     d2_out = best;
     return bpos;
 }
 
 // sweep_top2 with the filter (bounds from the third distance)
 __device__ __forceinline__ Top2 sweepf_top2(const float4* sq, const double2* sxy, const SweepF& f, int m, int dir, double uabs,
-                                            double qx, double qy, int seed, bool CENTRED) {
+                                            double qx, double qy, int seed, bool CENTRED, const float4* sbox = nullptr) {
     const SweepFQuery fq(f, dir, uabs, qx, qy);
     Top2 t;
     t.p1 = 0; t.p2 = -1;
@@ -600,9 +697,12 @@ __device__ __forceinline__ Top2 sweepf_top2(const float4* sq, const double2* sxy
     const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
     SweepFWalk w(from_seed ? seed - 1 : h0 - 1, h0, m, fq.u);
     const int skip = seeded ? seed : -1;                               // the seed is in the list already
+    int rounds = 0;
+    bool far = false;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         while (w.more()) {
+            if (sbox && ++rounds > SWEEP_FAR_ROUNDS) { far = true; break; }
             const SweepFRound r(sq, w, fq, W, T);
             const bool pr = r.pr && w.hi != skip, pl = r.pl && w.lo != skip;
             if (pr || pl) {
@@ -611,29 +711,16 @@ __device__ __forceinline__ Top2 sweepf_top2(const float4* sq, const double2* sxy
                     const int i = side == 0 ? w.hi : w.lo;
                     if (side == 0 ? pr : pl) {
                         const double s = sweep_d2(qx, qy, sxy[i]);
-                        if (s == t.s1 || s == t.s2) {
-                            // exact tie with a kept distance: order by original row (the rule everywhere: (distance, row) ascending)
-                            const int row = sweepf_row(side == 0 ? r.cr : r.cl), r1 = sweepf_row(sq[t.p1]);
-                            const int r2 = t.p2 >= 0 ? sweepf_row(sq[t.p2]) : 0x7fffffff;
-                            if (s < t.s1 || (s == t.s1 && row < r1)) { t.s3 = t.s2; t.s2 = t.s1; t.p2 = t.p1; t.s1 = s; t.p1 = i; }
-                            else if (s < t.s2 || row < r2) { t.s3 = t.s2; t.s2 = s; t.p2 = i; }
-                            else t.s3 = s;                             // tie with the second, lost on the row
-                        } else {
-                            const bool c1 = s < t.s1, c2 = s < t.s2, c3 = s < t.s3;
-                            t.s3 = c2 ? t.s2 : (c3 ? s : t.s3);
-                            t.s2 = c1 ? t.s1 : (c2 ? s : t.s2);
-                            t.p2 = c1 ? t.p1 : (c2 ? i : t.p2);
-                            t.s1 = c1 ? s : t.s1;
-                            t.p1 = c1 ? i : t.p1;
-                        }
+                        top2_insert(t, s, i, sweepf_row(side == 0 ? r.cr : r.cl), sq);
                     }
                 }
                 fq.bounds(t.s3, W, T);
             }
             r.advance(w);
         }
-        if (!fq.polar || !w.wrap(m)) break;
+        if (far || !fq.polar || !w.wrap(m)) break;
     }
+    if (far) sweepf_far_top2(sq, sxy, sbox, fq, m, qx, qy, t, T);
     return t;
 }
 

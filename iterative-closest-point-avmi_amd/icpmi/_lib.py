@@ -69,6 +69,10 @@ _SIGS = {
     "icpmi_rotation_search": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                         C.c_size_t, C.c_void_p]),
+    "icpmi_rotation_search_batch_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
+    "icpmi_rotation_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                              C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "icpmi_world_to_grid": (C.c_int, [C.c_void_p, C.c_int64, C.c_double, C.c_double, C.c_void_p, C.c_void_p]),
     "icpmi_bresenham_cells": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "icpmi_grid_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),

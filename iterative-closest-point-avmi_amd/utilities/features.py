@@ -17,6 +17,7 @@ import torch
 
 from icpmi import _lib
 from icpmi import batch as _b
+from icpmi.prealign import AngleTables, arange_rows, rotation_search_batch, run_icp_pair_batch  # noqa: F401
 
 VERBOSE = True      # the reference prints one line per search
 
@@ -46,28 +47,6 @@ def rotation_scores(src_rows, target, angles, shift):
                                                 float(shift[0]), float(shift[1]), _b._ptr(out), _b._stream()),
                "rotation_search")
     return out.cpu().numpy()
-
-
-def arange_rows(lo, hi, step):
-    """``np.arange(lo[k], hi[k], step)`` for every k at once -> (values [K, L], lengths [K]); rows are padded with
-    their last value.  Bit for bit NumPy's own numbers: arange takes ceil((stop - start) / step) elements and fills
-    them as start + i * delta with delta = (start + step) - start."""
-    lo = np.asarray(lo, dtype=np.float64).reshape(-1)
-    hi = np.asarray(hi, dtype=np.float64).reshape(-1)
-    step = np.float64(step)
-    n = np.ceil((hi - lo) / step)
-    n = np.where(np.isfinite(n) & (n > 0), n, 0).astype(np.int64)
-    L = int(n.max()) if len(n) else 0
-    i = np.arange(L, dtype=np.float64)[None, :]
-    delta = ((lo + step) - lo)[:, None]
-    vals = lo[:, None] + i * delta
-    if L > 1:
-        vals[:, 1] = lo + step
-    if L > 0:
-        vals[:, 0] = lo
-    last = np.clip(n - 1, 0, None)
-    vals = np.where(np.arange(L)[None, :] < n[:, None], vals, vals[np.arange(len(n)), last][:, None]) if L else vals
-    return vals, n
 
 
 class _SearchContext:
@@ -155,14 +134,8 @@ def rotation_search(source, target, voxel_size=0.3, angle_step_coarse=2.0, angle
     12-double read-back; the angle grids, their cos / sin and the final R, t are the reference's NumPy expressions."""
     src, tgt = _as_rows(source, "source"), _as_rows(target, "target")
     ctx = _SearchContext.get()
-    key = ("features", float(angle_step_coarse), float(angle_step_fine))
-    if key not in ctx.tables:
-        angles_coarse = np.deg2rad(np.arange(-180, 180, angle_step_coarse))    # features.py:221
-        lo = angles_coarse - np.deg2rad(angle_step_coarse)                     # features.py:227-229, for every possible winner
-        hi = angles_coarse + np.deg2rad(angle_step_coarse)
-        fine, fine_n = arange_rows(lo, hi, np.deg2rad(angle_step_fine))
-        ctx.tables[key] = (angles_coarse, fine, fine_n, ctx.device_table(angles_coarse, fine, fine_n))
-    angles_coarse, fine, fine_n, dtab = ctx.tables[key]
+    tab = AngleTables.get(ctx.dev, angle_step_coarse, angle_step_fine)            # features.py:221, 227-229 for every possible winner
+    angles_coarse, fine, fine_n, dtab = tab.coarse, tab.fine, tab.fine_n, tab.device_table
     rec = ctx.run(src, tgt, voxel_size, angles_coarse, fine, fine_n, dtab, True, (0.0, 0.0))
     if rec[0] < 5 or rec[1] < 5:                                               # features.py:203-204
         return np.eye(2), np.zeros(2), float("inf")

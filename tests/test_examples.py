@@ -169,8 +169,12 @@ def _oracle_backend():
             return oracle.icp(s, t, **kw)[:3]
 
         @staticmethod
-        def icp_batch(source, targets, R_init, t_init, **kw):
-            out = [oracle.icp(source, tg, R_init=R_init[k], t_init=t_init[k], **kw) for k, tg in enumerate(targets)]
+        def run_icp_pairs(source, targets, feat_cfg, icp_cfg):
+            out = []
+            for tg in targets:                                        # slam.py:53-98, candidate by candidate
+                R0, t0, _ = oracle.rotation_search(source, tg, feat_cfg["rotation_voxel_size"], feat_cfg["angle_step_coarse"],
+                                                   feat_cfg["angle_step_fine"])
+                out.append(oracle.icp(source, tg, R_init=R0, t_init=t0, **icp_cfg))
             return (np.array([o[0] for o in out]), np.array([o[1] for o in out]), np.array([o[2] for o in out]),
                     np.array([o[3]["iters"] for o in out]))
 

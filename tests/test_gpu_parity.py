@@ -1156,7 +1156,7 @@ def test_mixed_batch_of_scans_and_one_large_target(uicp):
         b = batch.IcpBatch(clouds, np.arange(B), np.arange(B, 2 * B), 1e-10, 40, 0.04, R_init=Ri, t_init=ti, method=method, **extra)
         res = b.run().cpu().numpy()
         cnt = b.vox.cnt.cpu().numpy()
-        assert cnt[2 * B - 1] > 4096 and cnt[B:2 * B - 1].max() <= 2048
+        assert len(big) > 4096 and cnt[2 * B - 1] > 2048 and cnt[B:2 * B - 1].max() <= 2048   # routed by capacity: the in-place search
         assert (res[:, 15] != 4).all(), res[:, 15]                         # nobody is ICPMI_ST_EMPTY
         for i in range(B):
             Ro, to, eo, io = oracle.icp(clouds[i], clouds[B + i], 1e-10, 40, 0.04, R_init=Ri[i], t_init=ti[i], method=method, **extra)
@@ -1170,8 +1170,8 @@ def test_pair_context_keeps_the_sweep_path_above_4096_rows_in_all(uicp):
     from icpmi import batch, synth
     rng = np.random.default_rng(5)
     segs = synth.maze_segments()
-    a = np.vstack([synth.scan((0.0, 0.0, 0.0), 31, segs=segs), rng.uniform(-3, 3, (52, 2))])
-    bb = np.vstack([synth.scan((0.1, -0.05, np.deg2rad(2.0)), 32, segs=segs), rng.uniform(-3, 3, (952, 2))])
+    a = np.vstack([synth.scan((5.0, 5.0, 0.0), 31, segs=segs), rng.uniform(-3, 3, (200, 2))])[:2100]
+    bb = np.vstack([synth.scan((5.1, 4.95, np.deg2rad(2.0)), 32, segs=segs), synth.scan((5.1, 4.95, np.deg2rad(2.1)), 33, segs=segs)])[:3000]
     assert len(a) == 2100 and len(bb) == 3000
     R, t, err = uicp.ICP(a, bb, 1e-10, 60, 0.005, method="point_to_line", normal_k=40)     # k > 31: the fast path only
     ctx = batch.PairContext.get()
@@ -1243,3 +1243,98 @@ def test_rccl_world_of_one_gathers_results_and_bands(uicp):
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
+
+
+# ── batched pre-alignment: rotation search of every pair of a batch, feeding the batched ICP (slam.py:53-98) ──
+@pytest.mark.parametrize("case", ["cfg", "default", "big_rotation", "tiny"])
+def test_rotation_search_batch_golden(uicp, case):
+    """The batch entry on the reference's golden pairs: R, t bit-equal (same arg-min on the same angle grid), and the
+    R_init / t_init it leaves on the device for the ICP are those numbers too."""
+    from icpmi import prealign
+    z = load_golden("rotation_search")
+    kw = z[f"{case}__kw"]
+    b = prealign.RotationSearchBatch([z[f"{case}__src"], z[f"{case}__tgt"]], [0], [1], kw[0], kw[1], kw[2])
+    b.run()
+    R, t, s, rec = b.results()
+    assert np.array_equal(R[0], z[f"{case}__R"]) and np.array_equal(t[0], z[f"{case}__t"])
+    ref = float(z[f"{case}__score"])
+    assert (np.isinf(s[0]) and np.isinf(ref)) or abs(s[0] - ref) < 1e-13
+    init = b.init.cpu().numpy()[0]
+    assert np.array_equal(init[:4].reshape(2, 2), z[f"{case}__R"]) and np.array_equal(init[4:], z[f"{case}__t"])
+    assert int(rec[0, 11]) == (1 if case == "tiny" else 0)
+
+
+def test_rotation_search_batch_512_pairs(uicp, libopt):
+    """512 loop-closure candidates (SURVEY section 8d geometry: within 3 m / 20 degrees of a shared current scan) in one
+    chain of launches: R, t of every pair bit-equal to the single-pair chain and (a sample) to the oracle; the bounded
+    search scores a fraction of the coarse angles and finds the arg-min of scoring them all."""
+    from icpmi import prealign, synth
+    from utilities import features
+    B = 512
+    srcs, tgts = synth.loop_closure_batch(B, seed0=83000, shared_source=True, max_offset=3.0, max_yaw_deg=20.0)
+    b = prealign.RotationSearchBatch([srcs[0]] + tgts, np.zeros(B, dtype=np.int32), np.arange(1, B + 1, dtype=np.int32),
+                                     0.15, 1.5, 0.1, max_rows_hint=1024)
+    b.run()
+    R, t, s, rec = b.results()
+    assert (rec[:, 11] == 0).all()
+    assert rec[:, 12].mean() < 60 and rec[:, 12].min() >= 1, rec[:, 12].mean()      # of 240 coarse angles
+    libopt.setenv("ICPMI_RS_BATCH", "full")
+    b.run()
+    Rf, tf, sf, recf = b.results()
+    assert (recf[:, 12] == 240).all()
+    assert np.array_equal(recf[:, :11], rec[:, :11])                                 # same winners, same exact scores
+    libopt.delenv("ICPMI_RS_BATCH")
+    features.VERBOSE = False
+    for i in range(0, B, 16):
+        R1, t1, s1 = features.rotation_search(srcs[0], tgts[i], 0.15, 1.5, 0.1)
+        assert np.array_equal(R[i], R1) and np.array_equal(t[i], t1) and abs(s[i] - s1) <= 1e-13 * max(1.0, s1), i
+    for i in range(0, B, 64):
+        Ro, to, so = oracle.rotation_search(srcs[0], tgts[i], 0.15, 1.5, 0.1)
+        assert np.array_equal(R[i], Ro) and np.array_equal(t[i], to), i
+    init = b.init.cpu().numpy()
+    assert np.array_equal(init[:, :4].reshape(B, 2, 2), R) and np.array_equal(init[:, 4:], t)
+
+
+def test_rotation_search_batch_edge_cases(uicp):
+    """Distinct sources, clouds of very different sizes, a pair with too few points, a pair above the capacity hint
+    (searched by the single-pair entry instead), duplicated and collinear targets."""
+    from icpmi import prealign, synth
+    from utilities import features
+    rng = np.random.default_rng(77)
+    a, bb = synth.config2_pair(9)
+    line = np.column_stack([np.linspace(-4, 4, 900), np.full(900, 1.0)]) + rng.normal(scale=0.002, size=(900, 2))
+    dup = np.repeat(rng.uniform(-3, 3, size=(150, 2)), 4, axis=0)
+    clouds = [a, bb, a[::7], bb[::3], rng.uniform(-0.1, 0.1, size=(40, 2)), line, dup, rng.uniform(-6, 6, size=(3000, 2))]
+    ps = [0, 2, 0, 4, 5, 6, 0, 7]
+    pt = [1, 3, 3, 1, 0, 1, 6, 1]
+    b = prealign.RotationSearchBatch(clouds, ps, pt, 0.3, 2.0, 0.2, max_rows_hint=640)
+    b.run()
+    R, t, s, rec = b.results()
+    assert int(rec[3, 11]) == 1 and np.array_equal(R[3], np.eye(2)) and np.isinf(s[3])        # 40 points in a 0.2 m square: < 5 voxels
+    assert int(rec[7, 11]) == 2                                                                # ~1 500 voxels > hint of 640
+    features.VERBOSE = False
+    for i in range(len(ps)):
+        R1, t1, s1 = features.rotation_search(clouds[ps[i]], clouds[pt[i]], 0.3, 2.0, 0.2)
+        assert np.array_equal(R[i], R1) and np.array_equal(t[i], t1), i
+        assert (np.isinf(s[i]) and np.isinf(s1)) or abs(s[i] - s1) <= 1e-13 * max(1.0, s1), i
+
+
+def test_run_icp_pair_batch_equals_per_pair_chain(uicp):
+    """_run_icp_pair for a batch (rotation search -> R_init, t_init on the device -> ICP) against (a) the same two steps
+    with the host in between — bit for bit — and (b) the oracle's rotation search + ICP."""
+    from icpmi import batch, prealign, synth
+    B = 96
+    srcs, tgts = synth.loop_closure_batch(B, seed0=91000, shared_source=True, max_offset=3.0, max_yaw_deg=20.0)
+    icp_cfg = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+    feat_cfg = dict(rotation_voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
+    R, t, err, info = prealign.run_icp_pair_batch(srcs[0], tgts, icp_cfg, feat_cfg)
+    R0, t0, _ = prealign.rotation_search_batch(srcs[0], tgts, 0.15, 1.5, 0.1)
+    R2, t2, err2, info2 = batch.icp_batch(srcs[0], tgts, 1e-10, 150, 0.04, R0, t0, "point_to_line", 12)
+    assert np.array_equal(R, R2) and np.array_equal(t, t2) and np.array_equal(err, err2) and np.array_equal(info["iters"], info2["iters"])
+    for i in range(0, B, 12):
+        Ro0, to0, _ = oracle.rotation_search(srcs[0], tgts[i], 0.15, 1.5, 0.1)
+        Ro, to, eo, io = oracle.icp(srcs[0], tgts[i], 1e-10, 150, 0.04, R_init=Ro0, t_init=to0, method="point_to_line", normal_k=12)
+        assert int(info["iters"][i]) == io["iters"], i
+        if io["iters"] < 150:                  # a pair that never settles (150 iterations of a limit cycle) has no transform to compare
+            assert rot_err(R[i], t[i], Ro, to) < FRO_TOL, i
+    assert (err < 0.05).mean() > 0.5, (err < 0.05).mean()     # pre-aligned candidates register; from 3 m / 20 degrees ICP alone does not
