@@ -117,7 +117,8 @@ int icpmi_nn_batch(const double* pts, const int32_t* off_dev, const int32_t* cnt
 /* ---- estimate_normals_2d, icp.py:51-76 ------------------------------------
  * k+1 nearest neighbours (self included, k clamped to n-1), 2x2 covariance,
  * eigenvector of the smaller eigenvalue, unit length.  Sign is arbitrary, as
- * in the reference (it cancels in the point-to-line solve).  k <= 31.
+ * in the reference (it cancels in the point-to-line solve).  k <= 31 here (the
+ * exhaustive companion of icpmi_nn_batch); icpmi_prepare_targets takes any k.
  * One workgroup per selected cloud: cloud_ids[n_sel] lists the clouds to
  * process (NULL = clouds 0..n_sel-1).  max_n bounds the rows of any selected
  * cloud; total_rows = off[C].  The workspace is only needed when max_n > 8192
@@ -167,8 +168,8 @@ int icpmi_icp_batch(const double* pts, const int32_t* off_dev, const int32_t* cn
  * or x-y) with the smallest expected search window, sort the cloud along it and
  * store the sorted points, the sorted->row map and the axis in `prepared`
  * (icpmi_prepared_bytes(total_rows, n_clouds) bytes).  normal_k >= 0 also
- * computes estimate_normals_2d (icp.py:51-76) with k = normal_k (any k for clouds of
- * at most 4096 rows; k <= 31 on larger ones): stored in sorted order inside
+ * computes estimate_normals_2d (icp.py:51-76) with k = normal_k (any k, as the reference:
+ * up to 31 from register lists, beyond that a wave per query): stored in sorted order inside
  * `prepared`, and in row order in out_normals if given.
  * normal_k < 0 skips normals (point_to_point).
  *

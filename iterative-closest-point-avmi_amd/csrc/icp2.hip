@@ -292,12 +292,11 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
         double px[ICP2_SMAX], py[ICP2_SMAX];
         int pos[ICP2_SMAX];
         // Movement budget of each row's match.  A search returns the two nearest
-        // target points and the distance d3 of the third.  While the row's
-        // displacement from where it was searched (the anchor) plus its current
-        // distance to the nearer of those two stays below d3, every other target
-        // point is still farther (triangle inequality), so the match is the better
-        // of the two — two distance evaluations instead of a search.  `budget` holds
-        // d3 (rounded down).  Exact: margins cover
+        // target points and the distance d3 of the third.  While the row is
+        // displaced from where it was searched (the anchor) by less than
+        // (d3 - d1)/2, every other target point is still farther than the nearer
+        // of those two (triangle inequality), so the match is the better of the
+        // two — two distance evaluations instead of a search.  Exact: margins cover
         // rounding, equal distances fall back on the row rule or on a new search.
         // Net displacement, so a pair that oscillates in a limit cycle (the usual
         // reason for running to max_iterations) stops searching too.
@@ -369,31 +368,24 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
 #pragma unroll
             for (int s = 0; s < ICP2_SMAX; ++s) {
                 const bool valid = s < S && s * THREADS + tid < N;
-                // The two kept candidates' distances first (nearly every row needs them anyway), then the test with the
-                // CURRENT distance dq to the better of the two: every other target point was at least d3 from the anchor,
-                // so it is at least d3 - delta from the row now (delta: the row's displacement since its search,
-                // |dx| + |dy| >= it), and the better kept candidate is THE nearest neighbour while dq < d3 - delta.
-                // (Round 2 tested delta < (d3 - d1) / 2, which implies this — dq <= d1 + delta — and is about half as
-                // generous: rows of a limit cycle slide along their wall, where dq hardly grows.)
-                const int pa = max(pos[s], 0), pb = pos2[s] >= 0 ? pos2[s] : pa;
-                const double2 c = sxy[pa], e = sxy[pb];
-                const double dx = px[s] - c.x, dy = py[s] - c.y;
-                const double ex = px[s] - e.x, ey = py[s] - e.y;
-                double q2 = 0.0, w2 = 0.0;
-                q2 += dx * dx;
-                q2 += dy * dy;
-                w2 += ex * ex;
-                w2 += ey * ey;
-                // upper bound of dq in single precision: (float) rounds within 2^-24, v_sqrt_f32 within an ulp
-                const float dq_up = __builtin_amdgcn_sqrtf((float)fmin(q2, w2)) * 1.000001f + 1e-30f;
-                const bool within = valid && (fabs(px[s] - (double)ax[s]) + fabs(py[s] - (double)ay[s])) * 1.000000001 + (double)dq_up < (double)budget[s];
+                // |dx| + |dy| >= the distance between the row and its anchor
+                // (Tried in round 3: testing delta + dq < d3 with the CURRENT distance dq to the better kept candidate — about
+                // twice as generous, 0.7 % instead of 2 % of the rows of a limit cycle search — costs 8 registers (a spill at
+                // six waves per SIMD) and the distances of the rows that then search after all: no faster, 5.11 against 5.07 ms.)
+                const bool within = valid && (fabs(px[s] - (double)ax[s]) + fabs(py[s] - (double)ay[s])) * 1.000000001 < (double)budget[s];
                 srch[s] = valid && !within;
-#ifdef ICP2_X_NOSEARCH_FROM          // experiment: an upper bound on what the late searches cost (WRONG results)
-                if (it >= ICP2_X_NOSEARCH_FROM && pos[s] >= 0) srch[s] = false;
-#endif
                 if (within) {
                     // straight-line: a missing second candidate stands in as the first (never better), and only an
                     // exact tie of the two distances takes a branch (to compare the rows)
+                    const int pa = pos[s], pb = pos2[s] >= 0 ? pos2[s] : pos[s];
+                    const double2 c = sxy[pa], e = sxy[pb];
+                    const double dx = px[s] - c.x, dy = py[s] - c.y;
+                    const double ex = px[s] - e.x, ey = py[s] - e.y;
+                    double q2 = 0.0, w2 = 0.0;
+                    q2 += dx * dx;
+                    q2 += dy * dy;
+                    w2 += ex * ex;
+                    w2 += ey * ey;
                     bool second_wins = w2 < q2;
                     if (w2 == q2 && pb != pa) {
                         if constexpr (FILT) second_wins = sweepf_row(lds_sq[pb]) < sweepf_row(lds_sq[pa]);
@@ -423,9 +415,9 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                         if constexpr (FILT) t2 = sweepf_top2(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], centred);
                         else t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], centred);
                         pos[s] = t2.p1; pos2[s] = t2.p2;
-                        const double d3 = sqrt(t2.s3);
-                        // the third distance, minus the rounding of the single-precision anchor; rounded down
-                        const double bud = d3 - 1e-13 * d3 - 1.3e-7 * (fabs(px[s]) + fabs(py[s]));
+                        const double d1 = sqrt(t2.s1), d3 = sqrt(t2.s3);
+                        // minus the rounding of the single-precision anchor; rounded down
+                        const double bud = (d3 - d1) * 0.4999999995 - 1e-13 * (d3 + d1) - 1.3e-7 * (fabs(px[s]) + fabs(py[s]));
                         float bf = (float)bud;
                         bf = bf - fabsf(bf) * 1e-6f;
                         budget[s] = t2.s3 < __builtin_inf() ? bf : __builtin_inff();

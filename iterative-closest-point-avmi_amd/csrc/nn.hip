@@ -73,9 +73,14 @@ template <int DIM, int S>
 static int launch_nn(const double* pts, const int32_t* off, const int32_t* cnt, const int32_t* ps,
                      const int32_t* pt, int n_pairs, int max_src_n, int32_t* out_idx, double* out_dist,
                      int out_stride, hipStream_t st) {
-    dim3 grid((max_src_n + NN_THREADS * S - 1) / (NN_THREADS * S), n_pairs);
-    nn_batch_kernel<DIM, S><<<grid, NN_THREADS, 0, st>>>(pts, off, cnt, ps, pt, out_idx, out_dist, out_stride);
-    ICPMI_LAUNCH_CHECK();
+    // the pair index is the grid's y: at most 65 535 per launch, so a larger batch goes down in slices
+    for (int p0 = 0; p0 < n_pairs; p0 += 65535) {
+        const int np = n_pairs - p0 < 65535 ? n_pairs - p0 : 65535;
+        dim3 grid((max_src_n + NN_THREADS * S - 1) / (NN_THREADS * S), np);
+        nn_batch_kernel<DIM, S><<<grid, NN_THREADS, 0, st>>>(pts, off, cnt, ps + p0, pt + p0, out_idx + (size_t)p0 * out_stride,
+                                                             out_dist + (size_t)p0 * out_stride, out_stride);
+        ICPMI_LAUNCH_CHECK();
+    }
     return ICPMI_OK;
 }
 
@@ -89,7 +94,6 @@ extern "C" int icpmi_nn_batch(const double* pts, const int32_t* off_dev, const i
     if (!pts || !off_dev || !pair_src || !pair_tgt || !out_idx || !out_dist) return ICPMI_ERR_ARG;
     if (n_pairs < 0 || max_src_n < 0 || out_stride < max_src_n || (dim != 2 && dim != 3)) return ICPMI_ERR_ARG;
     if (n_pairs == 0 || max_src_n == 0) return ICPMI_OK;
-    if (n_pairs > 65535) return ICPMI_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     // Rows per thread: enough workgroups to cover the chip first, then register
     // blocking (one LDS broadcast read feeds S evaluations per lane).

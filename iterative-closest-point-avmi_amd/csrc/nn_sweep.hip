@@ -64,7 +64,6 @@ extern "C" int icpmi_nn_prepared_batch(const double* pts, const int32_t* off_dev
     if (n_pairs < 0 || max_src_n < 0 || max_tgt_n < 0 || out_stride < max_src_n) return ICPMI_ERR_ARG;
     if (max_tgt_n > 4096) return ICPMI_ERR_UNSUPPORTED;
     if (n_pairs == 0 || max_src_n == 0) return ICPMI_OK;
-    if (n_pairs > 65535) return ICPMI_ERR_UNSUPPORTED;
     const unsigned char* b = (const unsigned char*)prepared;
     const double2* g_sxy = (const double2*)b;
     const int32_t* g_sorig = (const int32_t*)(b + (size_t)total_rows * 32);
@@ -73,9 +72,13 @@ extern "C" int icpmi_nn_prepared_batch(const double* pts, const int32_t* off_dev
     while (cap < max_tgt_n) cap <<= 1;
     const size_t lds = (size_t)cap * 20;
     if (hipFuncSetAttribute((const void*)nn_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP;
-    dim3 grid((max_src_n + NNS_THREADS - 1) / NNS_THREADS, n_pairs);
-    nn_sweep_kernel<<<grid, NNS_THREADS, lds, (hipStream_t)stream>>>(pts, off_dev, cnt_dev, pair_src, pair_tgt, g_sxy, g_sorig, g_dir,
-                                                                   out_idx, out_dist, out_second_sq, out_stride, cap);
-    ICPMI_LAUNCH_CHECK();
+    for (int p0 = 0; p0 < n_pairs; p0 += 65535) {              // the pair index is the grid's y: slices of at most 65 535 pairs
+        const int np = n_pairs - p0 < 65535 ? n_pairs - p0 : 65535;
+        dim3 grid((max_src_n + NNS_THREADS - 1) / NNS_THREADS, np);
+        nn_sweep_kernel<<<grid, NNS_THREADS, lds, (hipStream_t)stream>>>(
+            pts, off_dev, cnt_dev, pair_src + p0, pair_tgt + p0, g_sxy, g_sorig, g_dir, out_idx + (size_t)p0 * out_stride,
+            out_dist + (size_t)p0 * out_stride, out_second_sq ? out_second_sq + (size_t)p0 * out_stride : nullptr, out_stride, cap);
+        ICPMI_LAUNCH_CHECK();
+    }
     return ICPMI_OK;
 }

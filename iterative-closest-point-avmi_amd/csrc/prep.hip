@@ -166,30 +166,60 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
 // wave reduction picks the overall next — so the neighbours come out in the (distance, row) order every other path
 // sums them in: same lists, same arithmetic, same normals.  O(k M / 64) per query: a fallback, not a fast path.
 constexpr int ANYK_THREADS = 256;
+// first sorted position whose key is >= v (wave-uniform)
+__device__ __forceinline__ int anyk_lower_bound(const double2* sxy, int M, int dir, double v) {
+    int lo = 0, hi = M;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const double2 c = sxy[mid];
+        if (proj(dir, c.x, c.y) < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
 __global__ __launch_bounds__(ANYK_THREADS) void normals_anyk_kernel(
     const int32_t* __restrict__ off, const int32_t* __restrict__ cnt, const int32_t* __restrict__ cloud_ids, int k,
     const double2* __restrict__ g_sxy, double2* __restrict__ g_snrm, const int32_t* __restrict__ g_sorig,
-    double* __restrict__ out_normals, int sel_cap) {
+    const int32_t* __restrict__ g_dir, double* __restrict__ out_normals, int sel_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     int32_t* sel = reinterpret_cast<int32_t*>(dyn) + (size_t)wave_id() * sel_cap;
     const int c = cloud_ids ? cloud_ids[blockIdx.y] : blockIdx.y;
-    const int M = cnt ? cnt[c] : off[c + 1] - off[c];
-    if (M <= 0 || off[c + 1] - off[c] > PREP_MAX_POINTS) return;
+    const int M = cnt ? min(cnt[c], off[c + 1] - off[c]) : off[c + 1] - off[c];
+    const int dir = g_dir[c];
+    if (M <= 0 || dir < 0) return;
     const double2* sxy = g_sxy + off[c];
     const int32_t* sorig = g_sorig + off[c];
     double2* o_snrm = g_snrm + off[c];
     double* o_rows = out_normals ? out_normals + (size_t)off[c] * 2 : nullptr;
-    const int kk = min(k, M - 1) + 1;                           // icp.py:61,66: k clamped, self included
+    const int kk = min(min(k, M - 1) + 1, sel_cap);             // icp.py:61,66: k clamped, self included
     const int lane = lane_id();
     const int waves = gridDim.x * (ANYK_THREADS / ICPMI_WAVE);
     for (int s = blockIdx.x * (ANYK_THREADS / ICPMI_WAVE) + wave_id(); s < M; s += waves) {     // wave-uniform
         const double2 q = sxy[s];
+        // Only a window of the sort order can hold the k nearest: the 2 kk + 1 points around the query's own place
+        // contain at least kk points, so the kk-th nearest is no farther than the farthest of THEM (R), and every
+        // candidate has its key within kappa R of the query's (|du| <= d along x or y, <= sqrt(2) d on the diagonals).
+        // A rolling submap of 10 000 points then scans a few hundred per query, not all of them.  (Bearing order: no
+        // such bound — the whole cloud, at most 2 048 points.)
+        int lo = 0, hi = M;
+        if (dir < SWEEP_POLAR) {
+            const int a0 = max(0, s - kk), a1 = min(M - 1, s + kk);
+            double r2 = 0.0;
+            for (int i = a0 + lane; i <= a1; i += ICPMI_WAVE) r2 = fmax(r2, sweep_d2(q.x, q.y, sxy[i]));
+            r2 = wave_max(r2);
+            if (a1 - a0 + 1 >= kk) {
+                const double uq = proj(dir, q.x, q.y);
+                const double w = sqrt(r2) * 1.4142135623730951 * 1.000001 + 1e-9 * (1.0 + fabs(uq));
+                lo = anyk_lower_bound(sxy, M, dir, uq - w);
+                hi = anyk_lower_bound(sxy, M, dir, uq + w + 1e-9 * (1.0 + fabs(uq)));
+                hi = min(M, hi + 1);
+            }
+        }
         double last_d = -1.0;
         int last_row = -1;
         for (int j = 0; j < kk; ++j) {
             double bd = __builtin_inf();
             int brow = 0x7fffffff, bpos = -1;
-            for (int i = lane; i < M; i += ICPMI_WAVE) {
+            for (int i = lo + lane; i < hi; i += ICPMI_WAVE) {
                 const double d2 = sweep_d2(q.x, q.y, sxy[i]);
                 const int row = sorig[i];
                 const bool after = d2 > last_d || (d2 == last_d && row > last_row);
@@ -269,7 +299,7 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
                                         int32_t allow_polar, void* stream) {
     using namespace icpmi;
     if (!pts || !off_dev || !prepared || n_sel < 0 || n_clouds < 0 || total_rows < 0 || max_n < 0) return ICPMI_ERR_ARG;
-    if (normal_k > 31 && max_n > PREP_MAX_POINTS) return ICPMI_ERR_UNSUPPORTED;      // large clouds: register lists only
+    if (normal_k > 31 && (size_t)(normal_k + 1) * 4 * (ANYK_THREADS / ICPMI_WAVE) > 96 * 1024) return ICPMI_ERR_UNSUPPORTED;   // k beyond 6 143
     if (prepared_bytes < icpmi_prepared_bytes(total_rows, n_clouds, max_n)) return ICPMI_ERR_WORKSPACE;
     if (max_n > PREP_MAX_POINTS && !off_host) return ICPMI_ERR_ARG;       // sizes are needed on the host to route big clouds
     if (cloud_ids && max_n > PREP_MAX_POINTS && !cloud_ids_host) return ICPMI_ERR_ARG;
@@ -293,12 +323,12 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
             const int n = off_host[c + 1] - off_host[c];
             if (n <= PREP_MAX_POINTS) { small_max = n > small_max ? n : small_max; continue; }
             const size_t o = (size_t)off_host[c];
-            const int rc = prep_big_cloud(pts + o * 2, cnt_dev ? cnt_dev + c : nullptr, n, normal_k, g_sxy + o, g_snrm + o,
+            const int rc = prep_big_cloud(pts + o * 2, cnt_dev ? cnt_dev + c : nullptr, n, normal_k > 31 ? -1 : normal_k, g_sxy + o, g_snrm + o,
                                           g_sorig + o, g_dir + c, out_normals ? out_normals + o * 2 : nullptr, scratch,
                                           scratch_bytes, st);
             if (rc != ICPMI_OK) return rc;
         }
-        if (small_max == 0) return ICPMI_OK;
+        if (small_max == 0 && normal_k <= 31) return ICPMI_OK;
     }
     int npad = 64;
     while (npad < small_max) npad <<= 1;
@@ -336,15 +366,17 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
     // list capacity = k + 1 exactly for the usual k (5, 10 = reference default, 12 = config.yaml), else the next size up;
     // beyond 31 neighbours: sort only, then the any-k kernel on the sorted copy
     if (normal_k > 31) {
-        ICPMI_PREP_GO2(0, false);
+        if (small_max > 0) { ICPMI_PREP_GO2(0, false); }
         ICPMI_LAUNCH_CHECK();
-        const int sel_cap = (small_max + 63) / 64 * 64;
+        // the list of a query: k + 1 positions, at most the largest cloud
+        const int kcap = normal_k + 1 < max_n ? normal_k + 1 : max_n;
+        const int sel_cap = (kcap + 63) / 64 * 64;
         const size_t lds_k = (size_t)sel_cap * 4 * (ANYK_THREADS / ICPMI_WAVE);
         if (hipFuncSetAttribute((const void*)normals_anyk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return ICPMI_ERR_HIP;
         int per_cloud = 2048 / n_sel;
         per_cloud = per_cloud < 1 ? 1 : (per_cloud > 256 ? 256 : per_cloud);
         normals_anyk_kernel<<<dim3(per_cloud, n_sel), ANYK_THREADS, lds_k, st>>>(off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig,
-                                                                                  out_normals, sel_cap);
+                                                                                  g_dir, out_normals, sel_cap);
         ICPMI_LAUNCH_CHECK();
         return ICPMI_OK;
     }

@@ -270,7 +270,7 @@ __device__ __forceinline__ double rsb_score_angle(const double2* src_c, int n, c
             const double2 p = src_c[i];
             const double qx = (p.x * c + p.y * -s) + shx, qy = (p.x * s + p.y * c) + shy;   // src_c @ R.T + mu_t, features.py:216
             double d2;
-            (void)sweepf_nn(sq, sxy, filt, m, dir, uabs, qx, qy, -1, true, d2, sbox);
+            (void)sweepf_nn_far(sq, sxy, sbox, filt, m, dir, uabs, qx, qy, d2);
             const double d = sqrt(d2);                                  // KDTree distance ...
             acc += d * d;                                               // ... squared, features.py:218
         }

@@ -542,11 +542,106 @@ struct SweepFRound {
     }
 };
 
+// sweep_nn with the filter: sq = float32 images (padded by one entry at either end), sxy = exact points (read only
+// for candidates that pass)
+__device__ __forceinline__ int sweepf_nn(const float4* sq, const double2* sxy, const SweepF& f, int m, int dir, double uabs,
+                                         double qx, double qy, int seed, bool CENTRED, double& d2_out) {
+    const SweepFQuery fq(f, dir, uabs, qx, qy);
+    double best = __builtin_inf();
+    float W = __builtin_inff(), T = __builtin_inff();
+    int bpos = 0;
+    const bool seeded = seed >= 0 && seed < m;
+    if (seeded) {
+        best = sweep_d2(qx, qy, sxy[seed]); bpos = seed;
+        fq.bounds(best, W, T);
+    }
+    // a seed on the other side of the seam at +-pi is no place to start from (the walk would cross the whole array)
+    const bool from_seed = seeded && !CENTRED && !(fq.polar && fabsf(sq[seed].z - fq.u) > 3.0f);
+    const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
+    SweepFWalk w(from_seed ? seed - 1 : h0 - 1, h0, m, fq.u);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        while (w.more()) {
+            const SweepFRound r(sq, w, fq, W, T);
+            if (r.pr || r.pl) {                                        // might win (or tie): the exact test
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int i = side == 0 ? w.hi : w.lo;
+                    if (side == 0 ? r.pr : r.pl) {
+                        const double s = sweep_d2(qx, qy, sxy[i]);
+                        if (s == best && i != bpos) {                  // exact tie: the lowest original row wins
+                            if (sweepf_row(side == 0 ? r.cr : r.cl) < sweepf_row(sq[bpos])) bpos = i;
+                        }
+                        if (s < best) { best = s; bpos = i; }
+                    }
+                }
+                fq.bounds(best, W, T);
+            }
+            r.advance(w);
+        }
+        if (!fq.polar || !w.wrap(m)) break;
+    }
+    d2_out = best;
+    return bpos;
+}
+
+// sweep_top2 with the filter (bounds from the third distance)
+__device__ __forceinline__ Top2 sweepf_top2(const float4* sq, const double2* sxy, const SweepF& f, int m, int dir, double uabs,
+                                            double qx, double qy, int seed, bool CENTRED) {
+    const SweepFQuery fq(f, dir, uabs, qx, qy);
+    Top2 t;
+    t.p1 = 0; t.p2 = -1;
+    t.s1 = t.s2 = t.s3 = __builtin_inf();
+    float W = __builtin_inff(), T = __builtin_inff();
+    const bool seeded = seed >= 0 && seed < m;
+    if (seeded) { t.s1 = sweep_d2(qx, qy, sxy[seed]); t.p1 = seed; }
+    // a seed on the other side of the seam at +-pi is no place to start from (the walk would cross the whole array)
+    const bool from_seed = seeded && !CENTRED && !(fq.polar && fabsf(sq[seed].z - fq.u) > 3.0f);
+    const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
+    SweepFWalk w(from_seed ? seed - 1 : h0 - 1, h0, m, fq.u);
+    const int skip = seeded ? seed : -1;                               // the seed is in the list already
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        while (w.more()) {
+            const SweepFRound r(sq, w, fq, W, T);
+            const bool pr = r.pr && w.hi != skip, pl = r.pl && w.lo != skip;
+            if (pr || pl) {
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int i = side == 0 ? w.hi : w.lo;
+                    if (side == 0 ? pr : pl) {
+                        const double s = sweep_d2(qx, qy, sxy[i]);
+                        if (s == t.s1 || s == t.s2) {
+                            // exact tie with a kept distance: order by original row (the rule everywhere: (distance, row) ascending)
+                            const int row = sweepf_row(side == 0 ? r.cr : r.cl), r1 = sweepf_row(sq[t.p1]);
+                            const int r2 = t.p2 >= 0 ? sweepf_row(sq[t.p2]) : 0x7fffffff;
+                            if (s < t.s1 || (s == t.s1 && row < r1)) { t.s3 = t.s2; t.s2 = t.s1; t.p2 = t.p1; t.s1 = s; t.p1 = i; }
+                            else if (s < t.s2 || row < r2) { t.s3 = t.s2; t.s2 = s; t.p2 = i; }
+                            else t.s3 = s;                             // tie with the second, lost on the row
+                        } else {
+                            const bool c1 = s < t.s1, c2 = s < t.s2, c3 = s < t.s3;
+                            t.s3 = c2 ? t.s2 : (c3 ? s : t.s3);
+                            t.s2 = c1 ? t.s1 : (c2 ? s : t.s2);
+                            t.p2 = c1 ? t.p1 : (c2 ? i : t.p2);
+                            t.s1 = c1 ? s : t.s1;
+                            t.p1 = c1 ? i : t.p1;
+                        }
+                    }
+                }
+                fq.bounds(t.s3, W, T);
+            }
+            r.advance(w);
+        }
+        if (!fq.polar || !w.wrap(m)) break;
+    }
+    return t;
+}
+
 // ── far queries: boxes of blocks of the sort order ───────────────────────────────────────────────────
 // A walk visits every point whose key lies within the bound of the query's key: a query that is metres from every
 // target point (a pair started from a wrong pre-alignment, a rotation far from the right one) walks most of the
 // cloud — ~1 400 candidates instead of ~10 — and a wave waits for its longest lane.  So a walk that has taken
-// SWEEP_FAR_ROUNDS rounds gives up and the search is finished by a scan over BLOCKS of SWEEP_BLOCK consecutive sorted
+// SWEEP_FAR_ROUNDS rounds gives up (sweepf_nn_far, below) and the search is finished by a scan over BLOCKS of SWEEP_BLOCK consecutive sorted
 // positions, each with the bounding box of its float32 images (sbox[b] = min x, min y, max x, max y): a block whose box
 // is farther than the bound is skipped whole, the points of the others go through the same float32 filter and exact
 // test as in the walk.  In bearing order a block is a contiguous piece of wall (tight boxes: ~100 box tests and two or
@@ -597,67 +692,24 @@ __device__ __forceinline__ void sweepf_far_nn(const float4* sq, const double2* s
     }
 }
 
-// one exact candidate into a top-two list (the rule everywhere: (squared distance, original row) ascending)
-__device__ __forceinline__ void top2_insert(Top2& t, double s, int i, int row, const float4* sq) {
-    if (s == t.s1 || s == t.s2) {
-        const int r1 = sweepf_row(sq[t.p1]);
-        const int r2 = t.p2 >= 0 ? sweepf_row(sq[t.p2]) : 0x7fffffff;
-        if (s < t.s1 || (s == t.s1 && row < r1)) { t.s3 = t.s2; t.s2 = t.s1; t.p2 = t.p1; t.s1 = s; t.p1 = i; }
-        else if (s < t.s2 || row < r2) { t.s3 = t.s2; t.s2 = s; t.p2 = i; }
-        else t.s3 = s;                                                 // tie with the second, lost on the row
-    } else {
-        const bool c1 = s < t.s1, c2 = s < t.s2, c3 = s < t.s3;
-        t.s3 = c2 ? t.s2 : (c3 ? s : t.s3);
-        t.s2 = c1 ? t.s1 : (c2 ? s : t.s2);
-        t.p2 = c1 ? t.p1 : (c2 ? i : t.p2);
-        t.s1 = c1 ? s : t.s1;
-        t.p1 = c1 ? i : t.p1;
-    }
-}
-
-// finish a top-two search over all blocks.  The list holds positions only for its first two entries: a point met again
-// that is one of them is skipped; one that gave the third distance (or lost earlier) compares equal or worse and changes
-// nothing.  Entries of the list the walk had filled from candidates it met before giving up are therefore kept.
-__device__ __forceinline__ void sweepf_far_top2(const float4* sq, const double2* sxy, const float4* sbox, const SweepFQuery& fq, int m,
-                                                double qx, double qy, Top2& t, float& T) {
-    float W;
-    for (int b = 0; b * SWEEP_BLOCK < m; ++b) {
-        if (sweepf_box_s2(sbox[b], fq.x, fq.y) > T) continue;
-        const int i1 = min(m, (b + 1) * SWEEP_BLOCK);
-        for (int i = b * SWEEP_BLOCK; i < i1; ++i) {
-            const float4 c = sq[i];
-            const float ex = fq.x - c.x, ey = fq.y - c.y;
-            if (__builtin_fmaf(ex, ex, ey * ey) > T || i == t.p1 || i == t.p2) continue;
-            const double s = sweep_d2(qx, qy, sxy[i]);
-            top2_insert(t, s, i, sweepf_row(c), sq);
-            fq.bounds(t.s3, W, T);
-        }
-    }
-}
-
-// sweep_nn with the filter: sq = float32 images (padded by one entry at either end), sxy = exact points (read only
-// for candidates that pass); sbox (optional) = block boxes for queries far from the cloud
-__device__ __forceinline__ int sweepf_nn(const float4* sq, const double2* sxy, const SweepF& f, int m, int dir, double uabs,
-                                         double qx, double qy, int seed, bool CENTRED, double& d2_out, const float4* sbox = nullptr) {
+// sweepf_nn for callers whose queries may lie far from the cloud (the rotation search: most angles put the source metres
+// off the target): the same walk, abandoned after SWEEP_FAR_ROUNDS rounds for the scan over block boxes.  A separate
+// function on purpose — the same logic inside sweepf_nn / sweepf_top2 cost the fused ICP kernel 11 registers (spills at
+// six waves per SIMD) and a third of its speed on pairs that start close (measured, round 3).
+__device__ __forceinline__ int sweepf_nn_far(const float4* sq, const double2* sxy, const float4* sbox, const SweepF& f, int m, int dir,
+                                             double uabs, double qx, double qy, double& d2_out) {
     const SweepFQuery fq(f, dir, uabs, qx, qy);
     double best = __builtin_inf();
     float W = __builtin_inff(), T = __builtin_inff();
     int bpos = 0;
-    const bool seeded = seed >= 0 && seed < m;
-    if (seeded) {
-        best = sweep_d2(qx, qy, sxy[seed]); bpos = seed;
-        fq.bounds(best, W, T);
-    }
-    // a seed on the other side of the seam at +-pi is no place to start from (the walk would cross the whole array)
-    const bool from_seed = seeded && !CENTRED && !(fq.polar && fabsf(sq[seed].z - fq.u) > 3.0f);
-    const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
-    SweepFWalk w(from_seed ? seed - 1 : h0 - 1, h0, m, fq.u);
+    const int h0 = sweepf_lower_bound(sq, m, fq.u);
+    SweepFWalk w(h0 - 1, h0, m, fq.u);
     int rounds = 0;
     bool far = false;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         while (w.more()) {
-            if (sbox && ++rounds > SWEEP_FAR_ROUNDS) { far = true; break; }
+            if (++rounds > SWEEP_FAR_ROUNDS) { far = true; break; }
             const SweepFRound r(sq, w, fq, W, T);
             if (r.pr || r.pl) {                                        // might win (or tie): the exact test
 #pragma unroll
@@ -680,48 +732,6 @@ __device__ __forceinline__ int sweepf_nn(const float4* sq, const double2* sxy, c
     if (far) sweepf_far_nn(sq, sxy, sbox, fq, m, qx, qy, best, bpos, T);
     d2_out = best;
     return bpos;
-}
-
-// sweep_top2 with the filter (bounds from the third distance)
-__device__ __forceinline__ Top2 sweepf_top2(const float4* sq, const double2* sxy, const SweepF& f, int m, int dir, double uabs,
-                                            double qx, double qy, int seed, bool CENTRED, const float4* sbox = nullptr) {
-    const SweepFQuery fq(f, dir, uabs, qx, qy);
-    Top2 t;
-    t.p1 = 0; t.p2 = -1;
-    t.s1 = t.s2 = t.s3 = __builtin_inf();
-    float W = __builtin_inff(), T = __builtin_inff();
-    const bool seeded = seed >= 0 && seed < m;
-    if (seeded) { t.s1 = sweep_d2(qx, qy, sxy[seed]); t.p1 = seed; }
-    // a seed on the other side of the seam at +-pi is no place to start from (the walk would cross the whole array)
-    const bool from_seed = seeded && !CENTRED && !(fq.polar && fabsf(sq[seed].z - fq.u) > 3.0f);
-    const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
-    SweepFWalk w(from_seed ? seed - 1 : h0 - 1, h0, m, fq.u);
-    const int skip = seeded ? seed : -1;                               // the seed is in the list already
-    int rounds = 0;
-    bool far = false;
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        while (w.more()) {
-            if (sbox && ++rounds > SWEEP_FAR_ROUNDS) { far = true; break; }
-            const SweepFRound r(sq, w, fq, W, T);
-            const bool pr = r.pr && w.hi != skip, pl = r.pl && w.lo != skip;
-            if (pr || pl) {
-#pragma unroll
-                for (int side = 0; side < 2; ++side) {
-                    const int i = side == 0 ? w.hi : w.lo;
-                    if (side == 0 ? pr : pl) {
-                        const double s = sweep_d2(qx, qy, sxy[i]);
-                        top2_insert(t, s, i, sweepf_row(side == 0 ? r.cr : r.cl), sq);
-                    }
-                }
-                fq.bounds(t.s3, W, T);
-            }
-            r.advance(w);
-        }
-        if (far || !fq.polar || !w.wrap(m)) break;
-    }
-    if (far) sweepf_far_top2(sq, sxy, sbox, fq, m, qx, qy, t, T);
-    return t;
 }
 
 #endif

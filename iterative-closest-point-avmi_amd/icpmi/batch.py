@@ -122,12 +122,15 @@ def normals_set(cs, k, cloud_ids=None, out=None, workspace=None):
         n_sel = len(ids)
         max_n = int(np.diff(cs.off_host)[ids].max()) if n_sel else 0
         ids_t = torch.from_numpy(ids).to(cs.pts.device)
-    if max_n <= PREP_MAX_POINTS:
-        # sweep search on the axis-sorted copy (prep.hip); the sorted copy is a by-product
+    if max_n <= PREP_MAX_POINTS or k > 31:
+        # sweep search on the axis-sorted copy (prep.hip; clouds above 4096 rows through global memory); the sorted copy
+        # is a by-product.  Any k (the exhaustive kernel below holds its lists in registers: k <= 31).
         need = L.icpmi_prepared_bytes(cs.total_rows, cs.n_clouds, max_n)
         if workspace is None or workspace.numel() < need:
             workspace = torch.empty(need, dtype=torch.uint8, device=cs.pts.device)
-        check(L.icpmi_prepare_targets_ex(_ptr(cs.pts), _ptr(cs.off), None, _ptr(cs.cnt), _ptr(ids_t), None, n_sel,
+        ids_host = None if cloud_ids is None else np.ascontiguousarray(cloud_ids, dtype=np.int32)
+        check(L.icpmi_prepare_targets_ex(_ptr(cs.pts), _ptr(cs.off), cs.off_host.ctypes.data_as(C.c_void_p), _ptr(cs.cnt),
+                                         _ptr(ids_t), None if ids_host is None else ids_host.ctypes.data_as(C.c_void_p), n_sel,
                                          cs.n_clouds, cs.total_rows, max_n, int(k), _ptr(out), _ptr(workspace),
                                          workspace.numel(), 1, _stream()), "estimate_normals_2d")
         return out
@@ -274,6 +277,8 @@ class IcpBatch:
                                              len(self.tgt_ids), self.raw.n_clouds, self.raw.total_rows, self.max_tgt_n,
                                              self.normal_k if self.use_p2l else -1, None, _ptr(self.prepared),
                                              self.prepared.numel(), 1, st), "prepare_targets")
+        elif self.use_p2l and self.normal_k > 31:
+            normals_set(self.vox, self.normal_k, cloud_ids=self.tgt_ids, out=self.normals)      # any k: the prepare path
         elif self.use_p2l:
             check(L.icpmi_normals_2d_batch(_ptr(self.vox.pts), _ptr(self.vox.off), _ptr(self.vox.cnt),
                                            _ptr(self.tgt_ids_dev), len(self.tgt_ids), self.raw.total_rows,

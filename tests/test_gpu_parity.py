@@ -1338,3 +1338,45 @@ def test_run_icp_pair_batch_equals_per_pair_chain(uicp):
         if io["iters"] < 150:                  # a pair that never settles (150 iterations of a limit cycle) has no transform to compare
             assert rot_err(R[i], t[i], Ro, to) < FRO_TOL, i
     assert (err < 0.05).mean() > 0.5, (err < 0.05).mean()     # pre-aligned candidates register; from 3 m / 20 degrees ICP alone does not
+
+
+def test_more_than_31_neighbours_on_a_cloud_above_4096_rows(uicp):
+    """normal_k > 31 on a rolling-submap-sized cloud (it used to be 'unsupported' above 4 096 rows): the wave-per-query
+    search scans only the window of the sort order that can hold the k nearest.  Normals against the oracle, and a
+    point_to_line registration of a scan onto that cloud."""
+    from icpmi import batch, synth
+    segs = synth.maze_segments()
+    poses = synth.trajectory(40)
+    big = uicp.voxel_downsample(np.vstack([synth.to_world(synth.scan(p, 500 + i, segs=segs), p) for i, p in enumerate(poses)]), 0.04)
+    assert len(big) > 4096
+    for k in (40, 64):
+        got = uicp.estimate_normals_2d(big, k)
+        ref = oracle.normals_2d(big, k)
+        ok = np.abs(np.abs(np.sum(got * ref, axis=1)) - 1) < 1e-9
+        assert ok.mean() >= 0.99, (k, ok.mean())
+    cur = synth.scan(poses[20], 977, segs=segs)
+    th = poses[20][2] + np.deg2rad(1.0)
+    R0 = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    t0 = np.array(poses[20][:2]) + [0.05, -0.04]
+    R, t, err, info = batch.icp_batch([cur], [big], 1e-10, 60, 0.04, R0, t0, "point_to_line", 40)
+    Ro, to, eo, io = oracle.icp(cur, big, 1e-10, 60, 0.04, R_init=R0, t_init=t0, method="point_to_line", normal_k=40)
+    assert int(info["iters"][0]) == io["iters"] and rot_err(R[0], t[0], Ro, to) < FRO_TOL
+
+
+def test_nn_batches_beyond_65535_pairs(uicp):
+    """icpmi_nn_batch / icpmi_nn_prepared_batch used to refuse more than 65 535 pairs (the grid's y extent): now slices."""
+    from icpmi import batch
+    rng = np.random.default_rng(4)
+    C, B = 300, 70001
+    clouds = [rng.normal(size=(rng.integers(3, 9), 2)) for _ in range(C)]
+    cs = batch.CloudSet.from_numpy(clouds)
+    ps = rng.integers(0, C, size=B).astype(np.int32)
+    pt = rng.integers(0, C, size=B).astype(np.int32)
+    d, i = batch.nn_set(cs, ps, pt)
+    d2, i2 = batch.nn_set_sweep(cs, ps, pt)
+    d, i, d2, i2 = d.cpu().numpy(), i.cpu().numpy(), d2.cpu().numpy(), i2.cpu().numpy()
+    for b in (0, 1, 65534, 65535, 65536, 70000):
+        n = len(clouds[ps[b]])
+        do, io = oracle.nn(clouds[ps[b]], clouds[pt[b]])
+        assert np.array_equal(i[b, :n], io) and np.array_equal(d[b, :n], do), b
+        assert np.array_equal(i2[b, :n], io) and np.array_equal(d2[b, :n], do), b
