@@ -60,6 +60,15 @@ __device__ __forceinline__ bool world_to_cell(double w, double mn, double res, i
     return true;
 }
 
+// The same index with ONE multiplication: floor(fl((w - mn) / res)) can differ from floor((w - mn) * (1 / res)) only when
+// the product lies within a few ulp of an integer — then (and for anything out of range) the division is done after all.
+__device__ __forceinline__ bool world_to_cell_fast(double w, double mn, double res, double rinv, int& out) {
+    const double d = (w - mn) * rinv, r = rint(d);
+    if (!(fabs(d) < 4.0e8) || fabs(d - r) <= 1e-12 * fabs(d) + 1e-300) return world_to_cell(w, mn, res, out);
+    out = (int)floor(d);
+    return true;
+}
+
 // Walker over the cells of one ray.
 struct Ray {
     int m0, n0, sm, sn;       // start on major / minor axis, step signs
@@ -106,7 +115,11 @@ struct Ray {
         if (qq <= 0) return 0;
         if (qq > dmin) return n;
         const long long num = 2ll * dmaj * qq - dmaj + 1, den = 2ll * dmin;       // num > 0, den > 0 (qq <= dmin)
-        const long long k = (num + den - 1) / den;
+        // ceil(num / den) without a 64-bit integer division (a few hundred instructions on this machine, and every beam
+        // that crosses a tile pays two): the float64 quotient is within a few units of it (num < 2^61), exact products settle it
+        long long k = (long long)((double)num / (double)den);
+        while (k * den < num) ++k;
+        while (k > 0 && (k - 1) * den >= num) --k;
         return k > n ? n : (int)k;
     }
     // narrow [klo, khi) to the steps whose MINOR coordinate lies inside [lo, hi) (the offset grows with k)
@@ -584,6 +597,221 @@ __global__ __launch_bounds__(RT_THREADS) void ray_tile_step_kernel(GridDesc g, c
     } else ray_finalize_body(g, f, b - n_count, n_fin);
 }
 
+
+// ── the live update in ONE launch: a workgroup OWNS a piece of the window ─────────────────────────────────────────
+// One update_scan of the running SLAM loop (slam.py:552-557) is ~250 000 cell visits: microseconds of work, and the two
+// passes above are two dependent launches with a round trip of every counter through L2 atomics in between (9 + 5 us
+// of kernels, 18.6 us per call).  Here a workgroup owns a rectangle of cells — a 64 x 64 tile, or a 16 x 16 piece of the
+// 3 x 3 tiles around the origin, which every beam crosses — walks every beam's part inside it into LDS counters (a wave
+// = 64 consecutive beams at the same step; a lidar reports beams in angular order, so near the origin the lanes of a
+// wave sit in the same few cells and their runs merge into one LDS atomic each) and then applies the H / M replay and
+// the clip to its own cells of the grid directly: no counter grid, no second launch, nothing to zero afterwards.  Same
+// integer counts per cell as the other passes, same replay: the same grid bit for bit.
+constexpr int RO_THREADS = 1024;                                 // 16 waves: a 2 048-beam scan is two passes (what a piece at the
+                                                                 // origin waits for is its passes over ALL the beams)
+constexpr int RO_STEPS = 16;                                     // steps per walk item
+constexpr int RO_FAR = 64;                                       // pieces away from the origin: whole tiles (32 x 32 pieces quarter their
+                                                                 // walks but start four times the workgroups: 15.9 against 13.4 us)
+constexpr int RO_SUB0 = 8, RO_SUB1 = 16;                         // the origin's tile in 8 x 8 pieces, the 8 tiles around it in 16 x 16
+constexpr int RO_N0 = (RT_TILE / RO_SUB0) * (RT_TILE / RO_SUB0), RO_N1 = (RT_TILE / RO_SUB1) * (RT_TILE / RO_SUB1);
+constexpr int RO_NEAR = RO_N0 + 8 * RO_N1;                       // 64 + 128 workgroups for the 3 x 3 tiles around the origin
+
+__global__ __launch_bounds__(RO_THREADS) void ray_owner_kernel(GridDesc g, const double* __restrict__ origin,
+                                                              const double* __restrict__ hits, int nb, FinArgs f,
+                                                              int tiles_x, int tiles_y, unsigned long long* dbg) {
+#ifdef RO_X_TIMES        // diagnostic build: cycles per phase of every workgroup into the workspace (tools/time_livescan.py)
+    const unsigned long long tt0 = __builtin_readcyclecounter();
+    unsigned long long t_sel = 0, t_walk = 0;
+    if (threadIdx.x == 0) { dbg[4 * blockIdx.x] = 0; dbg[4 * blockIdx.x + 1] = 0; dbg[4 * blockIdx.x + 2] = 0; dbg[4 * blockIdx.x + 3] = 1; }
+#endif
+    __shared__ uint32_t cnt[RT_TILE * RT_TILE];
+    __shared__ int4 seg[2 * RO_THREADS];                             // this chunk's beams: hit cell, step range inside the rectangle
+    __shared__ uint16_t items[2 * RO_THREADS / ICPMI_WAVE * (RT_TILE / RO_STEPS)];   // (wave of beams << 8 | block of RO_STEPS steps)
+    __shared__ int n_items[2];                                       // by pass parity: the other one is reset while this one is read
+    const int tid = threadIdx.x, lane = lane_id();
+    // What this thread will need from HBM is asked for before anything else — its beams of the first chunk here, the cells
+    // it finalises as soon as the origin (itself a round trip) has told the workgroup which cells it owns: each is a ~1 us
+    // round trip, and the phases below are short chains of dependent steps with nothing to hide one behind.
+    constexpr int PER_CHUNK = 2;                                     // a chunk = 2 x 1 024 beams: a 2 048-beam scan is one chunk
+    double hwx[PER_CHUNK], hwy[PER_CHUNK];
+#pragma unroll
+    for (int j = 0; j < PER_CHUNK; ++j) {
+        const int i = j * RO_THREADS + tid;
+        hwx[j] = i < nb ? hits[2 * (size_t)i] : 0.0; hwy[j] = i < nb ? hits[2 * (size_t)i + 1] : 0.0;
+    }
+    int ox = 0, oy = 0;
+    if (!(world_to_cell(origin[0], g.min_x, g.res, ox) && world_to_cell(origin[1], g.min_y, g.res, oy))) return;   // mapping.py: int() raises
+    const int otx = (ox - g.wx0) >> 6, oty = (oy - g.wy0) >> 6;      // arithmetic shift: floor, also left of the window
+    // the rectangle this workgroup owns (uniform)
+    int x0, y0, x1, y1;
+    const int b = blockIdx.x;
+    if (b < RO_N0) {                                                 // the origin's own tile: 8 x 8 pieces of 8 x 8 cells
+        constexpr int PER = RT_TILE / RO_SUB0;
+        if (otx < 0 || otx >= tiles_x || oty < 0 || oty >= tiles_y) return;
+        x0 = g.wx0 + otx * RT_TILE + (b % PER) * RO_SUB0; y0 = g.wy0 + oty * RT_TILE + (b / PER) * RO_SUB0;
+        x1 = x0 + RO_SUB0; y1 = y0 + RO_SUB0;
+    } else if (b < RO_NEAR) {                                        // the eight tiles around it: 4 x 4 pieces of 16 x 16 cells
+        constexpr int PER = RT_TILE / RO_SUB1;
+        const int e = b - RO_N0, t8 = e / RO_N1, sub = e - t8 * RO_N1, t9 = t8 < 4 ? t8 : t8 + 1;   // 0..8 without the centre (4)
+        const int tcx = otx + t9 % 3 - 1, tcy = oty + t9 / 3 - 1;
+        if (tcx < 0 || tcx >= tiles_x || tcy < 0 || tcy >= tiles_y) return;
+        x0 = g.wx0 + tcx * RT_TILE + (sub % PER) * RO_SUB1; y0 = g.wy0 + tcy * RT_TILE + (sub / PER) * RO_SUB1;
+        x1 = x0 + RO_SUB1; y1 = y0 + RO_SUB1;
+    } else {                                                         // everywhere else (tiles_x, tiles_y count 64 x 64 tiles)
+        constexpr int PER = RT_TILE / RO_FAR;
+        const int t = b - RO_NEAR, fx = t % (tiles_x * PER), fy = t / (tiles_x * PER);
+        const int tcx = fx / PER, tcy = fy / PER;
+        if (tcy >= tiles_y || (abs(tcx - otx) <= 1 && abs(tcy - oty) <= 1)) return;   // the pieces above cover those
+        x0 = g.wx0 + fx * RO_FAR; y0 = g.wy0 + fy * RO_FAR;
+        x1 = x0 + RO_FAR; y1 = y0 + RO_FAR;
+    }
+    x1 = min(x1, g.wx1); y1 = min(y1, g.wy1);
+    if (x0 >= x1 || y0 >= y1) return;
+    const int w = x1 - x0, h = y1 - y0;
+    // the cells this thread finalises (this workgroup is their only writer)
+    constexpr int FIN = RT_TILE * RT_TILE / RO_THREADS;              // cells per thread at most
+    float old[FIN];
+#pragma unroll
+    for (int j = 0; j < FIN; ++j) {
+        const int c = j * RO_THREADS + tid;
+        old[j] = c < w * h ? f.log_odds[(size_t)(y0 + c / w) * g.nx + (x0 + c % w)] : 0.0f;
+    }
+    for (int c = tid; c < w * h; c += RO_THREADS) cnt[c] = 0u;
+    if (tid == 0) { n_items[0] = 0; n_items[1] = 0; }
+    __syncthreads();
+    // the rectangle in world coordinates, grown by two cells: a beam whose end points both lie on one side of it, or whose
+    // line passes all four corners on one side, cannot touch it (Bresenham stays within a cell of the line) — decided
+    // without the divisions of a cell index; nearly every beam of a tile away from the origin leaves here
+    const double wxa = g.min_x + ((double)x0 - 2.0) * g.res, wxb = g.min_x + ((double)x1 + 2.0) * g.res;
+    const double wya = g.min_y + ((double)y0 - 2.0) * g.res, wyb = g.min_y + ((double)y1 + 2.0) * g.res;
+    const double owx = origin[0], owy = origin[1];
+    const double rinv = 1.0 / g.res;
+    for (int base = 0; base < nb; base += PER_CHUNK * RO_THREADS) {  // uniform trip count
+#ifdef RO_X_TIMES
+        const unsigned long long ta = __builtin_readcyclecounter();
+#endif
+        const int par = (base / (PER_CHUNK * RO_THREADS)) & 1;
+#pragma unroll
+        for (int j = 0; j < PER_CHUNK; ++j) {                        // a wave's 64 beams are neighbours
+            const int i = base + j * RO_THREADS + tid;
+            int hx = 0, hy = 0, klo = 0, khi = 0;
+            bool maybe = i < nb;
+            if (maybe) {
+                // (comparisons with NaN are false: such a beam goes on to the cell index, which refuses it)
+                maybe = !((owx < wxa && hwx[j] < wxa) || (owx > wxb && hwx[j] > wxb) || (owy < wya && hwy[j] < wya) || (owy > wyb && hwy[j] > wyb));
+                const double dxw = hwx[j] - owx, dyw = hwy[j] - owy;
+                if (maybe && fabs(dxw) + fabs(dyw) > 4.0 * g.res) {
+                    const double c0 = dxw * (wya - owy) - dyw * (wxa - owx), c1 = dxw * (wya - owy) - dyw * (wxb - owx);
+                    const double c2 = dxw * (wyb - owy) - dyw * (wxa - owx), c3 = dxw * (wyb - owy) - dyw * (wxb - owx);
+                    maybe = !((c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0) || (c0 < 0 && c1 < 0 && c2 < 0 && c3 < 0));
+                }
+            }
+            if (maybe && world_to_cell_fast(hwx[j], g.min_x, g.res, rinv, hx) && world_to_cell_fast(hwy[j], g.min_y, g.res, rinv, hy)) {
+                if (hx >= x0 && hx < x1 && hy >= y0 && hy < y1) atomicAdd(&cnt[(hy - y0) * w + (hx - x0)], 0x10000u);   // mapping.py:124-129
+                // Bresenham stays inside the rectangle of its end points ...
+                bool cross = !(max(ox, hx) < x0 || min(ox, hx) >= x1 || max(oy, hy) < y0 || min(oy, hy) >= y1);
+                if (cross) {
+                    // ... and within one cell of the straight line: a rectangle (grown by a cell) whose corners all lie
+                    // strictly on one side of the line cannot be touched
+                    const long long dx = hx - ox, dy = hy - oy;
+                    const long long cxa = x0 - 1 - ox, cxb = x1 - ox, cya = y0 - 1 - oy, cyb = y1 - oy;
+                    const long long c0 = dx * cya - dy * cxa, c1 = dx * cya - dy * cxb, c2 = dx * cyb - dy * cxa, c3 = dx * cyb - dy * cxb;
+                    cross = !((c0 > 0 && c1 > 0 && c2 > 0 && c3 > 0) || (c0 < 0 && c1 < 0 && c2 < 0 && c3 < 0));
+                }
+                if (cross) {
+                    Ray ray;
+                    ray.init(ox, oy, hx, hy);
+                    if (ray.xmajor) { ray.clip_major(x0, x1, klo, khi); ray.clip_minor(y0, y1, klo, khi); }
+                    else { ray.clip_major(y0, y1, klo, khi); ray.clip_minor(x0, x1, klo, khi); }
+                }
+            }
+            // The walk is shared out as (64 neighbouring beams, block of RO_STEPS steps) items: a far tile is crossed by two
+            // or three waves' worth of beams for up to 64 steps each, and a step is a chain of dependent LDS operations
+            // that one wave alone would queue up 64 deep; 16 waves take a block each.
+            // blocks of RO_STEPS steps the longest of the wave's 64 segments needs (a segment inside a 64 x 64 rectangle has at
+            // most 64 steps): four ballots, no trip through LDS
+            const int len = khi - klo;
+            int nblk = 0;
+#pragma unroll
+            for (int bk = 0; bk < RT_TILE / RO_STEPS; ++bk) nblk += __ballot(len > bk * RO_STEPS) != 0ull ? 1 : 0;
+            seg[j * RO_THREADS + tid] = make_int4(hx, hy, klo, khi);
+            if (lane == 0 && nblk > 0) {
+                const int slot = atomicAdd(&n_items[par], nblk);
+                for (int bk = 0; bk < nblk; ++bk) items[slot + bk] = (uint16_t)((j * (RO_THREADS / ICPMI_WAVE) + wave_id()) << 8 | bk);
+            }
+            // the beams of the next chunk (a scan of more than 2 048 beams)
+            const int in = base + (PER_CHUNK + j) * RO_THREADS + tid;
+            if (in < nb) { hwx[j] = hits[2 * (size_t)in]; hwy[j] = hits[2 * (size_t)in + 1]; }
+        }
+        __syncthreads();
+#ifdef RO_X_TIMES
+        const unsigned long long tb = __builtin_readcyclecounter();
+        t_sel += tb - ta;
+#endif
+        const int total = n_items[par];
+        if (tid == 0) n_items[par ^ 1] = 0;                          // nobody touches it between this barrier and the next
+#ifndef RO_X_NOWALK
+        for (int it = wave_id(); it < total; it += RO_THREADS / ICPMI_WAVE) {       // free cells, mapping.py:135-139
+            const int e = items[it];
+            const int4 sg = seg[(e >> 8) * ICPMI_WAVE + lane];
+            const int k0 = sg.z + (e & 0xff) * RO_STEPS, k1 = min(sg.w, k0 + RO_STEPS);
+            Ray r2;
+            r2.init(ox, oy, sg.x, sg.y);
+            if (k0 < k1) r2.seek(k0);
+            // all the block's cells first, then all the neighbour exchanges, then the adds: the exchanges (LDS round trips)
+            // are in flight together instead of one per step
+            int cid[RO_STEPS], prev[RO_STEPS];
+#pragma unroll
+            for (int q = 0; q < RO_STEPS; ++q) {
+                cid[q] = -1;
+                if (k0 + q < k1) {
+                    int x, y;
+                    r2.cell(k0 + q, x, y);
+                    cid[q] = (y - y0) * w + (x - x0);
+                    r2.step();
+                }
+            }
+            // runs of equal cells in adjacent lanes become one atomic each: around the origin the 64 neighbouring beams of a
+            // wave sit in the same few cells (up to 64 lanes would queue on one LDS word), and further out, where neighbours
+            // share a cell two or three at a time, it still wins (plain adds there: 15.8 against 13.4 us for the kernel)
+#pragma unroll
+            for (int q = 0; q < RO_STEPS; ++q) prev[q] = __shfl_up(cid[q], 1, ICPMI_WAVE);
+#pragma unroll
+            for (int q = 0; q < RO_STEPS; ++q) {
+                const bool leader = lane == 0 || cid[q] != prev[q];
+                const unsigned long long lead = __ballot(leader);
+                if (leader && cid[q] >= 0) {
+                    const unsigned long long above = lane == 63 ? 0ull : (lead >> (lane + 1));
+                    const int run = above ? __ffsll((long long)above) : 64 - lane;
+                    atomicAdd(&cnt[cid[q]], (uint32_t)run);
+                }
+            }
+        }
+#endif
+        __syncthreads();                                             // seg and items are written again by the next chunk
+#ifdef RO_X_TIMES
+        t_walk += __builtin_readcyclecounter() - tb;
+#endif
+    }
+    // this rectangle's cells: H hit adds, then M miss adds, then the clip (mapping.py:129,139,141)
+#ifndef RO_X_NOFIN
+#pragma unroll
+    for (int j = 0; j < FIN; ++j) {
+        const int c = j * RO_THREADS + tid;
+        if (c >= w * h) break;
+        const uint32_t v = cnt[c];
+        if (v) f.log_odds[(size_t)(y0 + c / w) * g.nx + (x0 + c % w)] = apply_counts(old[j], v >> 16, v & 0xffffu, f.l_hit, f.l_miss, f.lo32, f.hi32, true);
+    }
+#endif
+#ifdef RO_X_TIMES
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long te = __builtin_readcyclecounter();
+        dbg[4 * blockIdx.x] = t_sel; dbg[4 * blockIdx.x + 1] = t_walk; dbg[4 * blockIdx.x + 2] = te - tt0; dbg[4 * blockIdx.x + 3] = 2 + (unsigned long long)(w * h);
+    }
+#endif
+}
+
 __global__ void world_to_grid_kernel(const double* __restrict__ w, long long n, double mn, double res, long long* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = (long long)floor((w[i] - mn) / res);
@@ -707,6 +935,21 @@ extern "C" int icpmi_grid_update_scans_box(float* log_odds, void* counts_ws, int
     const bool forced_tiles = rc_env && rc_env[0] == 't';
     const bool tiles_ok = box_host && !empty_window && !(rc_env && rc_env[0] == 'a') && hits &&
                           ((live_scans > 1 && window_tiles <= 768) || forced_tiles);
+    // One live scan with a box from the caller: the owner pass, a single launch (RAYCAST = owner forces it for any single
+    // scan with a box, atomic / tiles keep the passes above: the parity tests run all three).  It needs no clip of cells
+    // the scan does not touch (full_clip) and 16-bit counts.
+    if (live_scans == 1 && box_host && !empty_window && !full_clip && hits && (!rc_env || rc_env[0] == 'o')) {
+        int s1 = 0;
+        while (hit_off_host[s1 + 1] == hit_off_host[s1]) ++s1;
+        const int nb1 = hit_off_host[s1 + 1] - hit_off_host[s1];
+        const long long tx = (wx1 - wx0 + RT_TILE - 1) / RT_TILE, ty = (wy1 - wy0 + RT_TILE - 1) / RT_TILE;
+        if (nb1 > 0 && nb1 <= 65535 && tx * ty <= 4096) {
+            ray_owner_kernel<<<RO_NEAR + (int)(tx * ty) * (RT_TILE / RO_FAR) * (RT_TILE / RO_FAR), RO_THREADS, 0, st>>>(g, origins + 2 * (size_t)s1, hits + 2 * (size_t)hit_off_host[s1], nb1,
+                                                                               fin, (int)tx, (int)ty, (unsigned long long*)counts_ws);
+            ICPMI_LAUNCH_CHECK();
+            return ICPMI_OK;
+        }
+    }
     TileArgs ta{};
     ScanBox* box_sets = (ScanBox*)((unsigned char*)counts_ws + capacity * sizeof(uint32_t) + 256);
     ta.tiles_x = (wx1 - wx0 + RT_TILE - 1) / RT_TILE; ta.tiles_y = (wy1 - wy0 + RT_TILE - 1) / RT_TILE;

@@ -108,6 +108,13 @@ def config2_pair(seed=0):
     return a, b
 
 
+def _free_pose(x, y, clearance=0.25):
+    """Inside the room and not inside (or within `clearance` of) one of its boxes."""
+    if not (ROOM[0] + clearance < x < ROOM[2] - clearance and ROOM[1] + clearance < y < ROOM[3] - clearance):
+        return False
+    return not any(b[0] - clearance < x < b[2] + clearance and b[1] - clearance < y < b[3] + clearance for b in BOXES)
+
+
 def loop_closure_batch(n_pairs, seed0=1000, shared_source=False, max_offset=0.6, max_yaw_deg=6.0):
     """Candidate scan pairs of a loop closure (BASELINE config 5): the target pose lies within ``max_offset`` metres
     (uniform distance, uniform direction) and ``max_yaw_deg`` degrees (uniform) of the source pose.
@@ -121,10 +128,13 @@ def loop_closure_batch(n_pairs, seed0=1000, shared_source=False, max_offset=0.6,
     src_shared = scan(base, seed0 - 1)
     for i in range(n_pairs):
         rng = np.random.default_rng(seed0 + i)
-        d = rng.uniform(0.0, max_offset)
-        a = rng.uniform(-np.pi, np.pi)
-        th = np.deg2rad(rng.uniform(-max_yaw_deg, max_yaw_deg))
-        pose_t = (base[0] + d * np.cos(a), base[1] + d * np.sin(a), base[2] + th)
+        while True:                          # a sensor cannot stand inside a box or a wall: such draws are taken again
+            d = rng.uniform(0.0, max_offset)
+            a = rng.uniform(-np.pi, np.pi)
+            th = np.deg2rad(rng.uniform(-max_yaw_deg, max_yaw_deg))
+            pose_t = (base[0] + d * np.cos(a), base[1] + d * np.sin(a), base[2] + th)
+            if _free_pose(pose_t[0], pose_t[1]):
+                break
         srcs.append(src_shared if shared_source else scan(base, seed0 + 7919 * (i + 1)))
         tgts.append(scan(pose_t, seed0 + i))
     return srcs, tgts

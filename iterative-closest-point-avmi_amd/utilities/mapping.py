@@ -40,6 +40,8 @@ class OccupancyGrid2D:
         self._seq = 0                      # non-empty scans applied so far (selects counter grid / box slot)
         self._host = None                  # cached host copy of the grid
         self._full_clip = not (self.log_odds_min <= 0.0 <= self.log_odds_max)
+        self._stages = None                # pinned staging rows of update_scan (NumPy in)
+        self._call = None                  # converted constant arguments of the update call (see _apply)
         self.cell_updates = 0              # not tracked on the device; see update_scans()
 
     # ── the grid as the reference exposes it ─────────────────────────────────
@@ -108,7 +110,31 @@ class OccupancyGrid2D:
             return
         if hit_points.ndim != 2 or hit_points.shape[1] != 2:
             raise ValueError("hit_points must have shape (N, 2)")
-        self.update_scans(np.asarray(origin_xy, dtype=np.float64).reshape(1, 2), [hit_points])
+        # the call slam.py:557 makes once per scan: origin and hits go up in ONE asynchronous copy from a pinned buffer
+        # (two buffers in turn: the previous call's copy may still be in flight), the cell box comes from the host rows
+        n = hit_points.shape[0]
+        st = self._stage(n + 1)
+        h = st[0].numpy()
+        h[0] = np.asarray(origin_xy, dtype=np.float64).reshape(2)
+        h[1:n + 1] = hit_points
+        st[1][:n + 1].copy_(st[0][:n + 1], non_blocking=True)
+        st[2].record()
+        rows = h[:n + 1]
+        self._off1[1] = n
+        self._apply(st[1][:1], st[1][1:n + 1], self._off1, None, self._box_of(rows.min(axis=0), rows.max(axis=0)))
+
+    def _stage(self, rows):
+        """(pinned host rows, device rows, event of the last copy out of the host rows) — two sets used in turn."""
+        if self._stages is None or self._stages[0][0].shape[0] < rows:
+            cap = max(4096, 2 * rows)
+            self._stages = [(torch.empty((cap, 2), dtype=torch.float64).pin_memory(),
+                             torch.empty((cap, 2), dtype=torch.float64, device=self._dev), torch.cuda.Event()) for _ in range(2)]
+            self._stage_i = 0
+            self._off1 = np.zeros(2, dtype=np.int32)
+        self._stage_i ^= 1
+        st = self._stages[self._stage_i]
+        st[2].synchronize()                                        # its previous upload has left the pinned rows
+        return st
 
     def update_scans(self, origins, hits, rows=None):
         """Apply several scans in order (the replay of slam.py:271-277) without returning to the host.
@@ -180,24 +206,32 @@ class OccupancyGrid2D:
 
     def _apply(self, org, packed, off, rows=None, box=None):
         """org (S,2) and packed hits (sum N,2) are float64 device tensors; off is a host int32 array.
-        box: int32[4] cell bounds of all rays (``_cell_box``), computed here when not given."""
-        L = _lib.lib()
+        box: int32[4] cell bounds of all rays (``_cell_box``), computed here when not given.
+
+        This is the per-scan call of a SLAM loop, so the host side is kept short: the function pointer and the grid's and
+        the workspace's addresses are converted once, the raw stream handle is read without
+        building a torch.cuda.Stream."""
         S = len(off) - 1
         r0, r1 = (0, self.ny) if rows is None else (int(rows[0]), int(rows[1]))
         if not 0 <= r0 <= r1 <= self.ny:
             raise ValueError("rows must satisfy 0 <= begin <= end <= ny")
-        if self._ws is None:
-            self._ws = torch.zeros(L.icpmi_grid_workspace_bytes(self.ny, self.nx), dtype=torch.uint8, device=self._dev)
+        c = self._call
+        if c is None:
+            L = _lib.lib()
+            if self._ws is None:
+                self._ws = torch.zeros(L.icpmi_grid_workspace_bytes(self.ny, self.nx), dtype=torch.uint8, device=self._dev)
+            c = self._call = (L.icpmi_grid_update_scans_box, C.c_void_p(self._grid.data_ptr()), C.c_void_p(self._ws.data_ptr()),
+                              self._dev.index)
         if box is None:
             box = self._cell_box(org, packed)
-        _lib.check(L.icpmi_grid_update_scans_box(_b._ptr(self._grid), _b._ptr(self._ws), self.ny, self.nx,
-                                                 self.min_x, self.min_y, self.resolution, _b._ptr(org),
-                                                 _b._ptr(packed), off.ctypes.data_as(C.c_void_p), S,
-                                                 float(self.l_hit), float(self.l_miss), self.log_odds_min,
-                                                 self.log_odds_max, self._seq, 1 if self._full_clip else 0,
-                                                 r0, r1, box.ctypes.data_as(C.c_void_p) if box is not None else None,
-                                                 _b._stream()), "update_scan")
-        applied = int(np.count_nonzero(np.diff(off)))
+        # (the scalars are the object's public attributes, as in the reference: read at every call)
+        code = c[0](c[1], c[2], self.ny, self.nx, self.min_x, self.min_y, self.resolution, org.data_ptr(),
+                    packed.data_ptr() if packed is not None else None, off.ctypes.data, S, float(self.l_hit), float(self.l_miss),
+                    self.log_odds_min, self.log_odds_max, self._seq, 1 if self._full_clip else 0, r0, r1,
+                    box.ctypes.data if box is not None else None, torch._C._cuda_getCurrentRawStream(c[3]))
+        if code != 0:
+            _lib.check(code, "update_scan")
+        applied = (1 if off[1] > off[0] else 0) if S == 1 else int(np.count_nonzero(np.diff(off)))
         if r1 > r0:
             self._seq += applied
         if applied and (r0, r1) == (0, self.ny):

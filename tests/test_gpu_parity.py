@@ -313,10 +313,12 @@ def test_world_to_grid(umap):
 GRID_KW = dict(resolution=0.05, p_hit=0.85, p_miss=0.42, log_odds_min=-8.0, log_odds_max=8.0)
 
 
-@pytest.fixture(params=["tiles", "atomic"])
+@pytest.fixture(params=["tiles", "atomic", "owner"])
 def raypath(request, libopt):
-    """Both counting passes of the ray-cast: per tile in LDS (the default for a replay of several scans whose box the
-    caller knows) and integer atomics per (beam, cell) on the scan's counter grid (single scans, callers without a box)."""
+    """The three passes of the ray-cast: counters per tile in LDS added to a counter grid (the default for a replay of
+    several scans whose box the caller knows), integer atomics per (beam, cell) on the scan's counter grid (callers
+    without a box), and the single launch in which a workgroup owns a rectangle of cells and applies its counts itself
+    (the default for one live scan; replays under "owner" take their default pass)."""
     libopt.setenv("ICPMI_RAYCAST", request.param)      # "tiles" also sends single scans down the tile pass
     return request.param
 

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Diagnostic: one live update_scan (BASELINE config 4: 2 048 beams into the 2 242 x 2 402 grid), data resident. usage: time_livescan.py [reps]"""
+import os, sys, time
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "iterative-closest-point-avmi_amd")); sys.path.insert(0, REPO)
+import numpy as np, torch
+from icpmi import _lib
+if os.environ.get('ICPMI_LIB'):
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ['ICPMI_LIB'])
+import bench
+from icpmi import synth
+g, org, hits, cells = bench.raycast_workload(synth, 4)
+d_org = torch.from_numpy(org[:1]).cuda(); d_hits = torch.from_numpy(hits[0]).cuda()
+off = np.array([0, len(hits[0])], dtype=np.int32)
+box = g._cell_box(d_org, d_hits)
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+for _ in range(50):
+    g._apply(d_org, d_hits, off, box=box)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter(); e0.record()
+for _ in range(reps):
+    g._apply(d_org, d_hits, off, box=box)
+e1.record(); t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+wall = time.perf_counter() - t0
+print("timed() as bench.py:", bench.timed(torch, lambda: g._apply(d_org, d_hits, off, box=box)) * 1e6, "us")
+g.reset()
+print("timed() after reset:", bench.timed(torch, lambda: g._apply(d_org, d_hits, off, box=box)) * 1e6, "us")
+print(f"per call: wall {wall / reps * 1e6:.2f} us, device (events) {e0.elapsed_time(e1) / reps * 1e3:.2f} us, host enqueue {t_host / reps * 1e6:.2f} us; box {box}")
+
+if os.environ.get("RO_TIMES"):          # diagnostic library (-DRO_X_TIMES): cycles per phase of every workgroup
+    g._ws.zero_(); torch.cuda.synchronize()
+    g._apply(d_org, d_hits, off, box=box); torch.cuda.synchronize()
+    d = g._ws[:8 * 4 * 1024].view(torch.int64).cpu().numpy().reshape(-1, 4)
+    d = d[d[:, 3] >= 2]
+    o = np.argsort(-d[:, 2])
+    print("workgroups that worked:", len(d), "slowest (select, walk, total cycles, cells+2):")
+    print(d[o[:12]])
+    print("median total", np.median(d[:, 2]), "median select", np.median(d[:, 0]), "median walk", np.median(d[:, 1]))
+    g._ws.zero_()
