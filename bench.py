@@ -79,7 +79,7 @@ def csrc_signature():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
 
 
 def pmc_traffic(kernel_substr, workgroups):
@@ -92,13 +92,14 @@ def pmc_traffic(kernel_substr, workgroups):
     if doc.get("csrc_sha256") != csrc_signature():
         return None, (f"profiles/{os.path.basename(PMC_TRAFFIC)} was collected on csrc {doc.get('csrc_sha256')}, this build is "
                       f"{csrc_signature()}: stale, not quoted")
-    # A batch is up to three launches of the fused ICP code (csrc/icp2.hip: every pair up to 12 iterations on `workgroups`
-    # workgroups; the pairs still running, on a sixteenth as many; the pairs with wide clouds, on a thirty-second): the
-    # bytes of the batch are their sum.  kernel_substr may name several kernels ("a|b").
+    # A batch is up to four launches of the fused ICP code (csrc/icp2.hip: every pair up to 12 iterations on `workgroups`
+    # workgroups; the pairs still running, one per workgroup of an eighth as many, and whatever that leaves on 256 more; the
+    # pairs with wide clouds, on a thirty-second): the bytes of the batch are their sum.  Below 1 024 pairs: one launch.
     B = workgroups
-    grid_of = {"icp2_resume": max(256, B // 16), "icp2_wide": min(B, max(256, B // 32))}
-    key = [k for k in doc.get("kernels", {}) for sub in kernel_substr.split("|")
-           if sub in k and f"[{grid_of.get(sub, B)} workgroups]" in k]
+    grids = {"icp2_fused_kernel": B}
+    if B >= 1024:
+        grids.update({"icp2_resume_kernel": max(256, B // 8), "icp2_resume_rest_kernel": 256, "icp2_wide_kernel": min(B, max(256, B // 32))})
+    key = [k for k in doc.get("kernels", {}) for name, grid in grids.items() if name + "<" in k and f"[{grid} workgroups]" in k]
     if not key:
         return None, "kernel/grid not in the committed PMC summary"
     total = sum(doc["kernels"][k]["hbm_bytes_per_launch"] for k in key)
@@ -169,7 +170,7 @@ class Leg:
              "algorithmic_bytes_per_launch": alg_bytes, "pair_iterations_per_launch": float(it.sum()),
              "note": "algorithmic bytes = sum over pairs of iterations x (28 N + 16 M), N/M rows after voxel filtering; the "
                      "kernel keeps a pair on chip for all its iterations, so it is bound by its instruction stream "
-                     "(VALU + divergence), not by HBM: see traffic and profiles/r02_pmc_instruction_mix.json"}
+                     "(VALU + divergence), not by HBM: see traffic and profiles/r03_pmc_instruction_mix.json"}
         if b.fast:
             r["traffic"], r["traffic_source"] = pmc_traffic("icp2_fused|icp2_resume|icp2_wide", B)
             if r["traffic"]:

@@ -242,6 +242,7 @@ struct RsbArgs {
     const int32_t* pair_tgt;
     const double2* g_sxy;         // prepared targets
     const int32_t* g_sorig;
+    const float* g_skey;          // float32 bearings (bearing order)
     const int32_t* g_dir;
     const double* coarse_cs;
     int n_coarse;
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     const int dir = a.g_dir[tc];
     int status = RSB_ST_OK;
     if (n < 5 || m < 5) status = RSB_ST_FEW;                           // features.py:203-204: identity, zeros, inf
-    else if (n > a.cap || m > a.cap || dir < 0 || dir > 3) status = RSB_ST_CAPACITY;
+    else if (n > a.cap || m > a.cap || dir < 0 || dir > SWEEP_POLAR) status = RSB_ST_CAPACITY;
     if (status != RSB_ST_OK) {                                         // uniform per workgroup, before any barrier
         if (tid == 0) {
             for (int i = 0; i < RSB_REC_DOUBLES; ++i) rec[i] = 0.0;
@@ -318,12 +319,22 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     float4* sq = reinterpret_cast<float4*>(dyn + (size_t)a.cap * 32) + 1;      // one padding entry at either end
     float4* sbox = reinterpret_cast<float4*>(dyn + (size_t)a.cap * 48 + 32);   // boxes of blocks of 16 sorted positions (sweep.hpp: far queries)
 
+#ifdef RSB_X_TIMES          // diagnostic build: cycles per phase in the record (tools/time_prealign.py RSB_TIMES=1)
+#define RSB_T(k) tph[k] = __builtin_readcyclecounter()
+    unsigned long long tph[8];
+#else
+#define RSB_T(k)
+#endif
+    RSB_T(0);
     // ── 1. stage the pair ────────────────────────────────────────────────────
     if (tid == 0) { rt_bits = 0; rho_bits = 0; n_evals = 0; best_score = __builtin_inf(); }
     const double2* gx = a.g_sxy + a.off[tc];
     const int32_t* go = a.g_sorig + a.off[tc];
+    const float* gk = a.g_skey + a.off[tc];
+    // float32 images: relative to the point in the middle of the sort order, or — bearing order — to the frame origin the
+    // bearings are taken about (as the fused ICP kernel stages them)
     SweepF filt{0.0, 0.0, 0.0, 0.0f, 0.0f};
-    {
+    if (dir != SWEEP_POLAR) {
         const double2 o = gx[m >> 1];
         filt.ox = o.x; filt.oy = o.y; filt.uo = proj(dir, o.x, o.y);
     }
@@ -332,7 +343,8 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     for (int i = tid; i < m; i += RSB_THREADS) {
         const double2 p = gx[i];
         sxy[i] = p;
-        const float4 q = make_float4((float)(p.x - filt.ox), (float)(p.y - filt.oy), (float)(proj(dir, p.x, p.y) - filt.uo), __int_as_float(go[i]));
+        const float4 q = make_float4((float)(p.x - filt.ox), (float)(p.y - filt.oy),
+                                     dir == SWEEP_POLAR ? gk[i] : (float)(proj(dir, p.x, p.y) - filt.uo), __int_as_float(go[i]));
         sq[i] = q;
         rmax = fmaxf(rmax, fmaxf(fabsf(q.x), fabsf(q.y)));
     }
@@ -354,6 +366,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     const double2 c_lo = sxy[0], c_hi = sxy[m - 1];
     const double uabs = fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y)));
 
+    RSB_T(1);
     // ── 2. distance field: lower bounds on the distance to the target, in the frame of the float32 images ─────
     // The rotated source lies in the disc of radius rho about mu_t; the grid covers the square around it.
     const float H = __int_as_float(rho_bits) * 1.00001f + 1e-3f;       // half side
@@ -393,6 +406,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     }
     __syncthreads();
 
+    RSB_T(2);
     // ── 3. lower bound of every coarse score: a wave per angle, one look-up per row ──────────────
     const int n_coarse = a.n_coarse;
     if (a.prune) {
@@ -422,6 +436,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     } else
         for (int k = tid; k < n_coarse; k += RSB_THREADS) lb[k] = -__builtin_inff();
     __syncthreads();
+    RSB_T(3);
     // ── 4. order by bound (rank by counting), then exact scores in that order ─────────────
     for (int i = tid; i < RSB_MAX_ANGLES; i += RSB_THREADS) scores[i] = __builtin_inf();      // (the field's memory: see above)
     for (int k = tid; k < n_coarse; k += RSB_THREADS) {
@@ -431,6 +446,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
         order[rank] = (short)k;
     }
     __syncthreads();
+    RSB_T(4);
     const bool prune = a.prune != 0;
     // (items are dealt to the waves round-robin — no work counter: a counter bumped by lane 0 and broadcast with
     // readfirstlane inside this loop was jump-threaded by the compiler into a per-lane loop whose other 63 lanes read item 0
@@ -454,6 +470,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     const int coarse_evals = n_evals;
     const int nf = a.max_fine > 0 ? min(a.fine_cnt[kbest], a.max_fine) : 0;
     __syncthreads();
+    RSB_T(5);
     // ── 5. the fine grid around the winner, features.py:227-232 ───────────────
     for (int i = tid; i < RSB_MAX_ANGLES; i += RSB_THREADS) scores[i] = __builtin_inf();
     if (tid == 0) { best_score = __builtin_inf(); n_evals = 0; }
@@ -471,6 +488,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     __syncthreads();
     first_argmin_init(sh_arg);
     const int jbest = nf > 0 ? first_argmin(scores, nf, sh_arg) : 0;
+    RSB_T(6);
     if (tid == 0) {
         for (int i = 0; i < RSB_REC_DOUBLES; ++i) rec[i] = 0.0;
         rec[RSREC_NS] = (double)n; rec[RSREC_NT] = (double)m;
@@ -479,6 +497,9 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
         rec[RSREC_FSCORE] = nf > 0 ? scores[jbest] : __builtin_nan("");
         rec[RSBREC_STATUS] = (double)(nf > 0 ? RSB_ST_OK : RSB_ST_NO_FINE);
         rec[RSBREC_EVALS] = (double)coarse_evals; rec[RSBREC_FEVALS] = (double)n_evals;
+#ifdef RSB_X_TIMES
+        for (int k = 0; k < 6; ++k) rec[k] = (double)(tph[k + 1] - tph[k]);      // stage, field, bounds, order, coarse, fine
+#endif
         if (init) {
             if (nf > 0) {
                 // R = [[ca, -sa], [sa, ca]], t = mu_t - R @ mu_s (features.py:235-237).  The 2 x 2 by 2 product is a BLAS
@@ -627,14 +648,17 @@ extern "C" int icpmi_rotation_search_batch(const double* pts, const int32_t* off
     int rc = icpmi_voxel_downsample_batch(pts, off_dev, off_host, n_clouds, 2, voxel_size, vox, cnt, vws, icpmi_voxel_workspace_bytes(max_n), stream);
     if (rc != ICPMI_OK) return rc;
     rsb_means_kernel<<<(n_clouds + RSB_MEAN_WAVES - 1) / RSB_MEAN_WAVES, RSB_MEAN_WAVES * ICPMI_WAVE, 0, st>>>(vox, off_dev, cnt, n_clouds, means);
-    // search order of the targets (projection axes only: the queries are not in the target's sensor frame)
+    // search order of the targets: a projection or, for scans in their sensor frame, the bearing (the library's estimate; any
+    // order is exact for any query — RS_BATCH = "projection" keeps to the projections)
+    const char* oe = option("RS_BATCH");
     rc = icpmi_prepare_targets_ex(vox, off_dev, off_host, cnt, tgt_ids, nullptr, tgt_ids ? n_tgt_ids : n_clouds, n_clouds, total_rows, max_n, -1,
-                                  nullptr, prepared, prepared_bytes, 0, stream);
+                                  nullptr, prepared, prepared_bytes, oe && oe[0] == 'p' ? 0 : 1, stream);
     if (rc != ICPMI_OK) return rc;
     RsbArgs a;
     a.vox = vox; a.off = off_dev; a.cnt = cnt; a.means = means; a.pair_src = pair_src; a.pair_tgt = pair_tgt;
     a.g_sxy = (const double2*)prepared;
     a.g_sorig = (const int32_t*)(prepared + (size_t)total_rows * 32);
+    a.g_skey = (const float*)(prepared + (size_t)total_rows * 36);
     a.g_dir = (const int32_t*)(prepared + (size_t)total_rows * 40);
     a.coarse_cs = coarse_cs; a.n_coarse = n_coarse; a.fine_cs = fine_cs; a.fine_cnt = fine_cnt; a.max_fine = max_fine;
     a.records = out_records; a.init = out_init;

@@ -30,5 +30,7 @@ rec = b.search.records.cpu().numpy()[:B]
 print(f"B={B} offset<={off} yaw<={yaw}: search {ts[:,0].mean():.3f} ms, voxel+prepare {ts[:,1].mean():.3f} ms, icp {ts[:,2].mean():.3f} ms; "
       f"registered {(res[:,12] < 0.05).mean():.3f}, iterations {int(res[:,14].sum())} (n150 {(res[:,14] == 150).sum()}), "
       f"exact angles coarse {rec[:,12].mean():.1f} (max {int(rec[:,12].max())}, >40: {(rec[:,12] > 40).sum()}) fine {rec[:,13].mean():.1f}, fine score median {np.median(rec[:,10]):.4f}")
+if os.environ.get("RSB_TIMES"):
+    print("cycles per phase (stage, field, bounds, order, coarse, fine): median", np.median(rec[:, :6], axis=0).astype(int), "max", rec[:, :6].max(axis=0).astype(int))
 if os.environ.get("SAVE_REC"):
     np.save(os.environ["SAVE_REC"], np.hstack([rec, res]))
