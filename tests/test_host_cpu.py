@@ -244,7 +244,8 @@ def test_bench_refuses_stale_pmc_traffic(tmp_path, monkeypatch):
     spec.loader.exec_module(bench)
     sig = bench.csrc_signature()
     assert re.fullmatch(r"[0-9a-f]{16}", sig)
-    doc = {"csrc_sha256": sig, "kernels": {"void icpmi::icp2_x<512> [64 workgroups]": {"hbm_bytes_per_launch": 123}}}
+    doc = {"csrc_sha256": sig, "kernels": {"void icpmi::icp2_fused_kernel<512, 2, true, true>(icpmi::Icp2Args) [64 workgroups]": {"hbm_bytes_per_launch": 123},
+                                           "void icpmi::icp2_resume_rest_kernel<512, 2, true, true>(icpmi::Icp2Args, int) [256 workgroups]": {"hbm_bytes_per_launch": 7}}}
     f = tmp_path / "pmc.json"
     f.write_text(json.dumps(doc))
     monkeypatch.setattr(bench, "PMC_TRAFFIC", str(f))
