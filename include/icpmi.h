@@ -83,10 +83,11 @@ const char* icpmi_strerror(int code);
  * unsets).  Names (with or without the ICPMI_ prefix): ICP2_SIDE (0: no side
  * streams), ICP2_SHAPE ("TxS": workgroup shape of the fused ICP), ICP2_FILTER
  * (0: no float32 filter), ICP2_STAGES (1: one launch, 2: two stages also for
- * point_to_point), ICP2_SPLIT (sub-batches of a small batch: 1 = off), ICP2_TAIL
- * (0: no tail shape), POLAR (0 never / 2 always the bearing order), PREP_KNN
- * (grid | sweep), RAYCAST (atomic | tiles | owner), RT_WGS, RS_BATCH.  Unknown
- * names: ICPMI_ERR_ARG.  Must not race with running calls.
+ * point_to_point), POLAR (0 never / 2 always the bearing order), PREP_KNN
+ * (grid | sweep), RAYCAST (atomic | tiles | owner: the pass of the occupancy
+ * update), RT_WGS (resident workgroups of the tile pass), RS_BATCH (full: the
+ * batched rotation search scores every angle; projection: no bearing order).
+ * Unknown names: ICPMI_ERR_ARG.  Must not race with running calls.
  * icpmi_shutdown synchronises and destroys the side streams and events the
  * library made (they are made again on demand); call it before unloading. */
 int icpmi_set_option(const char* name, const char* value);
@@ -284,6 +285,10 @@ int icpmi_bresenham_cells(const int32_t* segs, const int64_t* cell_off, int32_t 
 
 /* update_scan, mapping.py:103-141, for n_scans consecutive scans (n_scans = 1
  * is the reference call; more is the _rebuild_map replay of slam.py:271-277).
+ * One scan with a cell box from the caller (icpmi_grid_update_scans_box) and no
+ * full_clip is ONE launch: workgroups own rectangles of the box, count in LDS and
+ * apply the replay and the clip to their own cells; the counter workspace is not
+ * touched.
  * log_odds: float32 (ny, nx), updated in place.  Scan s has origin
  * origins[2s..2s+1] and hits rows [hit_off_host[s], hit_off_host[s+1]) of
  * hits (world frame, float64).  Per cell the result equals the reference's

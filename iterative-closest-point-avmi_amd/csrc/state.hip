@@ -5,7 +5,7 @@
 //    calls getenv.
 //  * side streams: up to ICPMI_SIDE_STREAMS streams per device with a fork event and one join event each, made on
 //    first use (option ICP2_SIDE = 0: never), used by launchers that overlap independent launches of one call (the
-//    wide-cloud launch of the fused ICP beside its second stage; the sub-batches of a small batch).  A launcher
+//    wide-cloud launch of the fused ICP beside its second stage).  A launcher
 //    holds the lock for its whole fork / launch / join sequence, so two host threads never interleave their event
 //    records; every caller stream of a device shares these streams (calls from several streams overlap their side
 //    work only as far as the side streams differ).  icpmi_shutdown destroys them.
@@ -21,8 +21,8 @@
 
 namespace icpmi {
 
-static const char* const kOptionNames[] = {"ICP2_SIDE", "ICP2_SHAPE", "ICP2_FILTER", "ICP2_STAGES", "ICP2_SPLIT", "ICP2_TAIL",
-                                           "POLAR", "PREP_KNN", "RAYCAST", "RT_WGS", "RS_BATCH"};
+static const char* const kOptionNames[] = {"ICP2_SIDE", "ICP2_SHAPE", "ICP2_FILTER", "ICP2_STAGES", "POLAR", "PREP_KNN", "RAYCAST",
+                                           "RT_WGS", "RS_BATCH"};
 
 struct Options {
     std::mutex mu;
