@@ -57,7 +57,10 @@ def self_launch(n_gpus, argv):
         print(json.dumps({"launch": cmd}), flush=True)
         return 0
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL needs it on this host driver
+    # The image exports HSA_ENABLE_IPC_MODE_LEGACY=0 (its host driver only supports dmabuf IPC, without which RCCL's
+    # cross-process buffer sharing fails with hipIpcGetMemHandle: invalid argument — the task environment's statement, NOT
+    # verified by this repo: no multi-rank RCCL run has been recorded yet); kept when set, defaulted when not.
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
     for ln in proc.stdout:                                       # the JSON line to stdout, everything else to stderr
@@ -175,6 +178,10 @@ class Leg:
             r["traffic"], r["traffic_source"] = pmc_traffic("icp2_fused|icp2_resume|icp2_wide", B)
             if r["traffic"]:
                 r["traffic_GBps"] = round(r["traffic"] / (self.k_ms * 1e-3) / 1e9, 1)
+                r["traffic_frac"] = round(r["traffic"] / (self.k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            r["limiter"] = ("vector instruction issue (profiles/r03_pmc_instruction_mix.json): `frac` prices ALGORITHMIC bytes, most "
+                            "of which never cross HBM — the pair stays on chip for all its iterations; `traffic_frac` is the measured "
+                            "HBM utilisation")
         return r
 
 
@@ -266,7 +273,9 @@ def main():
     if world > 1:
         line["collective"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
                               "library": "RCCL over xGMI" if backend == "nccl" else "gloo (rehearsal)",
-                              "what": "one all_gather_into_tensor of 128-B result records per step, inside the timed region"}
+                              "what": "one all_gather_into_tensor of 128-B result records per step, inside the timed region",
+                              "status": "multi-rank RCCL path: exercised by gloo world-2 CPU tests and a world-of-one RCCL run on "
+                                        "one GPU (tests); no multi-GPU run had been recorded when this bench was written"}
 
     # ── BASELINE config 5 as written: 512 candidate pairs in all (one GPU: one batch; N GPUs: 512/N pairs each +
     #    the all_gather) — strong scaling, same K steps, same barriers ──
