@@ -239,6 +239,18 @@ int icpmi_rotation_search(const double* pts, int32_t n_src, int32_t n_tgt, doubl
                           int32_t centred, double shift_x, double shift_y,
                           double* out_record, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Translation refinement of the submap variant, slam.py:161-181, on the state icpmi_rotation_search left behind
+ * (search_workspace: the same buffer, untouched since; record: its out_record; the same angle tables): the filtered
+ * source rotated by the winning angle (NumPy's own (n, 2) @ (2, 2) arithmetic) and placed at (pred_x, pred_y), its
+ * nearest target rows, np.percentile(d^2, 80) with linear interpolation, and the mean of (matched - rotated) over the
+ * rows at or below it — out4 (device): refined t (2; the predicted position when fewer than 5 rows qualify, slam.py:
+ * 175-181), the inlier count, the percentile.  n_src / n_tgt: the RAW row counts passed to the search; n_src <= 2048
+ * (ICPMI_ERR_UNSUPPORTED above: refine on the host from the filtered clouds). */
+size_t icpmi_rotation_refine_workspace_bytes(int32_t n_src);
+int icpmi_rotation_refine(const void* search_workspace, int32_t n_src, int32_t n_tgt, const double* record,
+                          const double* coarse_cs, const double* fine_cs, int32_t max_fine,
+                          double pred_x, double pred_y, double* out4, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- batched pre-alignment: rotation_search (utilities/features.py:165-242) for every pair of a batch — the first
  * half of _run_icp_pair (slam.py:53-98), which slam.py:575-579 calls once per loop-closure candidate ----------------
  * pts / off_dev / off_host: a cloud set of RAW 2-D clouds (at most 4096 rows each); pair b searches the rotation of

@@ -208,6 +208,109 @@ __global__ void rs_finish_kernel(const double* __restrict__ coarse, int n_coarse
 }
 
 
+// ── translation refinement of the submap variant, slam.py:161-181 ─────────────────────────────────────────────────
+// After the sweeps: rotate the (filtered) source by the winning angle, place it at the predicted position, match every
+// row to its nearest target point, keep the closest 80 % (np.percentile, linear interpolation) and take the mean of
+// (matched - rotated) over them.  Two launches: the matches (K1 scan, a row per thread), then one workgroup for the
+// percentile and the mean.  Every step in the reference's arithmetic: the rotated rows are NumPy's (n, 2) @ (2, 2) —
+// a BLAS gemm whose element is fma(y, R[c][1], x * R[c][0]) (OpenBLAS, FMA kernels; checked on random inputs in the
+// build container) — the distances the k-d tree's (direct differences, IEEE sqrt), squared again; the percentile
+// numpy's _lerp on the (n - 1) * 0.8-th order statistic; the mean a row-by-row sum divided by the count.
+constexpr int RSR_MAX_ROWS = 2048;            // rows the finishing workgroup holds in LDS
+constexpr int RSR_THREADS = 1024;
+
+__device__ __forceinline__ void rsr_best_cs(const double* __restrict__ rec, const double* __restrict__ coarse_cs,
+                                            const double* __restrict__ fine_cs, int max_fine, double& ca, double& sa) {
+    const int k = (int)rec[RSREC_K], nf = (int)rec[RSREC_NF], j = (int)rec[RSREC_J];
+    const double* cs = nf > 0 ? fine_cs + ((size_t)k * max_fine + j) * 2 : coarse_cs + (size_t)k * 2;   // slam.py:157-159
+    ca = cs[0]; sa = cs[1];
+}
+
+// row i: rot[i] = src[i] @ R.T, d2[i] = (distance to the nearest target)^2 as KDTree.query returns it squared, idx[i] = that target row
+__global__ __launch_bounds__(RS_THREADS) void rs_refine_match_kernel(
+    const double* __restrict__ vox, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt, const double* __restrict__ rec,
+    const double* __restrict__ coarse_cs, const double* __restrict__ fine_cs, int max_fine, double pred_x, double pred_y,
+    double2* __restrict__ rot, double* __restrict__ dsq, int32_t* __restrict__ idx) {
+    __shared__ __attribute__((aligned(16))) double tile[RS_TILE_DOUBLES];
+    const int n = cnt[0], m = cnt[1];
+    const int first = blockIdx.x * RS_THREADS;
+    if (first >= n || m <= 0) return;                              // uniform per workgroup
+    double ca, sa;
+    rsr_best_cs(rec, coarse_cs, fine_cs, max_fine, ca, sa);
+    const double* src = vox + (size_t)off[0] * 2;
+    const double* tgt = vox + (size_t)off[1] * 2;
+    const int i = first + threadIdx.x, ii = i < n ? i : n - 1;
+    const double x = src[2 * ii], y = src[2 * ii + 1];
+    const double rx = __builtin_fma(y, -sa, x * ca), ry = __builtin_fma(y, ca, x * sa);   // src @ R_best.T, slam.py:168
+    double p[1][2] = {{rx + pred_x, ry + pred_y}};                 // placed, slam.py:169
+    double best[1] = {__builtin_inf()};
+    int bestj[1] = {0};
+    for (int t0 = 0; t0 < m; t0 += RS_TILE_POINTS) {
+        const int c = min(RS_TILE_POINTS, m - t0);
+        __syncthreads();
+        const int padded = stage_targets<2>(tgt + (size_t)t0 * 2, c, tile);
+        __syncthreads();
+        nn_scan_tile<2, 1>(tile, padded, t0, p, best, bestj);
+    }
+    if (i < n) {
+        const double d = sqrt(best[0]);
+        rot[i] = make_double2(rx, ry); dsq[i] = d * d; idx[i] = bestj[0];    // slam.py:170-171
+    }
+}
+
+// out[0..1] = refined t (or the predicted position), out[2] = inliers, out[3] = the 80th percentile
+__global__ __launch_bounds__(RSR_THREADS) void rs_refine_finish_kernel(
+    const double* __restrict__ vox, const int32_t* __restrict__ off, const int32_t* __restrict__ cnt,
+    const double2* __restrict__ rot, const double* __restrict__ dsq, const int32_t* __restrict__ idx,
+    double pred_x, double pred_y, double* __restrict__ out) {
+    __shared__ double v[RSR_MAX_ROWS];
+    __shared__ double2 diff[RSR_MAX_ROWS];
+    __shared__ double stat[2];
+    __shared__ int n_in;
+    const int n = cnt[0], m = cnt[1], tid = threadIdx.x;
+    if (n < 5 || m < 5 || n > RSR_MAX_ROWS) {                      // slam.py:128-129 (the caller returns the prediction)
+        if (tid == 0) { out[0] = pred_x; out[1] = pred_y; out[2] = 0.0; out[3] = __builtin_nan(""); }
+        return;
+    }
+    const double* tgt = vox + (size_t)off[1] * 2;
+    for (int i = tid; i < n; i += RSR_THREADS) {
+        v[i] = dsq[i];
+        const double2 r = rot[i];
+        const int j = idx[i];
+        diff[i] = make_double2(tgt[2 * j] - r.x, tgt[2 * j + 1] - r.y);           // matched - rotated_src, slam.py:178-179
+    }
+    if (tid == 0) n_in = 0;
+    __syncthreads();
+    // np.percentile(v, 80), method "linear": order statistics lo = floor((n - 1) * 0.8) and lo + 1 by rank counting
+    const double vi = (double)(n - 1) * 0.8;                        // np.true_divide(80, 100) = 0.8
+    const int lo = (int)floor(vi), hi = min(lo + 1, n - 1);
+    for (int i = tid; i < n; i += RSR_THREADS) {
+        const double x = v[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) { const double w = v[j]; rank += (w < x || (w == x && j < i)) ? 1 : 0; }
+        if (rank == lo) stat[0] = x;
+        if (rank == hi) stat[1] = x;
+    }
+    __syncthreads();
+    const double A = stat[0], B = stat[1], t = vi - (double)lo, d = B - A;
+    double thresh = A + d * t;                                      // numpy _lerp
+    if (t >= 0.5) thresh = B - d * (1.0 - t);
+    int mine = 0;
+    for (int i = tid; i < n; i += RSR_THREADS) mine += v[i] <= thresh ? 1 : 0;     // slam.py:174
+    atomicAdd(&n_in, mine);
+    __syncthreads();
+    const int k = n_in;
+    if (tid < 2) {
+        // np.mean(..., axis=0) of a (k, 2) array: the rows in order, one column per lane
+        double s = 0.0;
+        const double* col = reinterpret_cast<const double*>(diff) + tid;
+        for (int i = 0; i < n; ++i)
+            if (v[i] <= thresh) s += col[2 * i];
+        out[tid] = k >= 5 ? s / (double)k : (tid == 0 ? pred_x : pred_y);          // slam.py:175-181
+        if (tid == 0) { out[2] = (double)k; out[3] = thresh; }
+    }
+}
+
 // ── the search for a BATCH of pairs: the pre-alignment half of _run_icp_pair (slam.py:53-98 -> features.py:165-242) ──
 // The reference scores every angle of the coarse sweep in full (~240 k-d tree sweeps per pair).  Only the arg-min of
 // those scores matters (features.py:223), and nearly all of them lose by a wide margin: a rotated source that sticks
@@ -675,6 +778,37 @@ extern "C" int icpmi_rotation_search_batch(const double* pts, const int32_t* off
     if (hipFuncSetAttribute((const void*)rotation_search_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ICPMI_ERR_HIP;
     rotation_search_batch_kernel<<<n_pairs, RSB_THREADS, lds, st>>>(a);
+    ICPMI_LAUNCH_CHECK();
+    return ICPMI_OK;
+}
+
+
+// scratch of the refinement: rotated rows | squared distances | matched rows (n_src of each)
+extern "C" size_t icpmi_rotation_refine_workspace_bytes(int32_t n_src) {
+    if (n_src < 0) return 0;
+    return rs_align((size_t)n_src * 16) + rs_align((size_t)n_src * 8) + rs_align((size_t)n_src * 4) + 256;
+}
+
+extern "C" int icpmi_rotation_refine(const void* search_workspace, int32_t n_src, int32_t n_tgt, const double* record,
+                                     const double* coarse_cs, const double* fine_cs, int32_t max_fine,
+                                     double pred_x, double pred_y, double* out4, void* scratch, size_t scratch_bytes, void* stream) {
+    using namespace icpmi;
+    if (!search_workspace || !record || !coarse_cs || !out4 || !scratch || n_src <= 0 || n_tgt <= 0 || max_fine < 0) return ICPMI_ERR_ARG;
+    if (max_fine > 0 && !fine_cs) return ICPMI_ERR_ARG;
+    if (n_src > RSR_MAX_ROWS) return ICPMI_ERR_UNSUPPORTED;             // (raw rows: the filtered count is at most that)
+    if (scratch_bytes < icpmi_rotation_refine_workspace_bytes(n_src)) return ICPMI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned char* w = (const unsigned char*)search_workspace;
+    const int32_t* off = (const int32_t*)w;
+    const int32_t* cnt = off + 4;
+    const double* vox = (const double*)(w + 256);
+    unsigned char* s = (unsigned char*)scratch;
+    double2* rot = (double2*)s;
+    double* dsq = (double*)(s + rs_align((size_t)n_src * 16));
+    int32_t* idx = (int32_t*)((unsigned char*)dsq + rs_align((size_t)n_src * 8));
+    rs_refine_match_kernel<<<(n_src + RS_THREADS - 1) / RS_THREADS, RS_THREADS, 0, st>>>(vox, off, cnt, record, coarse_cs, fine_cs, max_fine,
+                                                                                          pred_x, pred_y, rot, dsq, idx);
+    rs_refine_finish_kernel<<<1, RSR_THREADS, 0, st>>>(vox, off, cnt, rot, dsq, idx, pred_x, pred_y, out4);
     ICPMI_LAUNCH_CHECK();
     return ICPMI_OK;
 }

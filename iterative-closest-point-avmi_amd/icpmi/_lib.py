@@ -69,6 +69,9 @@ _SIGS = {
     "icpmi_rotation_search": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                         C.c_size_t, C.c_void_p]),
+    "icpmi_rotation_refine_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "icpmi_rotation_refine": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double,
+                                        C.c_double, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "icpmi_rotation_search_batch_workspace_bytes": (C.c_size_t, [C.c_int32] * 3),
     "icpmi_rotation_search_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                               C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,

@@ -139,10 +139,11 @@ def submap_rotation_search(source_local, submap_global, predicted_pose, angle_ra
 
     Sweeps the rotation of the scan about the predicted pose (coarse grid, then a fine grid around the winner) as
     ONE chain of launches (``icpmi_rotation_search``: voxel filters, both sweeps and both arg-mins on the device,
-    one 12-double read-back), then refines the translation with one nearest-neighbour step over the closest 80 %
-    of the matches.  The angle grids are the reference's NumPy expressions (every fine grid that can follow a coarse
-    winner is tabulated up front); the percentile and the inlier mean stay NumPy on distances and indices the
-    kernels produce exactly as the reference's KDTree does — R and t are the reference's bit for bit.
+    nothing read back in between), then refines the translation with one nearest-neighbour step over the closest 80 %
+    of the matches — on the device too (``icpmi_rotation_refine``: NumPy's own arithmetic for the rotated rows, the
+    percentile and the mean; scans of more than 2 048 raw rows refine on the host from the filtered clouds) — and reads
+    back 16 doubles.  The angle grids are the reference's NumPy expressions (every fine grid that can follow a coarse
+    winner is tabulated up front); R and t are the reference's bit for bit.
     """
     from utilities.features import _SearchContext, arange_rows
     _b.require_gpu()
@@ -171,9 +172,34 @@ def submap_rotation_search(source_local, submap_global, predicted_pose, angle_ra
                                                       _b._ptr(dtab[1]) if max_fine else None, _b._ptr(dtab[2]) if max_fine else None,
                                                       max_fine, 0, float(pred_t[0]), float(pred_t[1]), _b._ptr(ctx.rec), _b._ptr(ws),
                                                       ws.numel(), _b._stream()), "submap_rotation_search")
-    rec = ctx.rec.cpu().numpy()
+    L = _b._lib.lib()
+    on_device = ns <= 2048                                                    # the refinement's finishing workgroup holds the rows in LDS
+    if on_device:
+        # translation: one nearest-neighbour centroid step over the closest 80 %, slam.py:161-181, still on the device
+        need = L.icpmi_rotation_refine_workspace_bytes(ns)
+        if getattr(ctx, "ref_ws", None) is None or ctx.ref_ws.numel() < need:
+            ctx.ref_ws = torch.empty(2 * need, dtype=torch.uint8, device=ctx.dev)
+            ctx.ref_out = torch.zeros(4, dtype=torch.float64, device=ctx.dev)
+        _b._lib.check(L.icpmi_rotation_refine(_b._ptr(ws), ns, nt, _b._ptr(ctx.rec), _b._ptr(dtab[0]),
+                                              _b._ptr(dtab[1]) if max_fine else None, max_fine, float(pred_t[0]), float(pred_t[1]),
+                                              _b._ptr(ctx.ref_out), _b._ptr(ctx.ref_ws), ctx.ref_ws.numel(), _b._stream()),
+                      "submap_rotation_search (refinement)")
+        both = torch.cat([ctx.rec, ctx.ref_out]).cpu().numpy()                # one read-back
+        rec, ref = both[:12], both[12:]
+    else:
+        rec = ctx.rec.cpu().numpy()
     if rec[0] < 5 or rec[1] < 5:                                              # slam.py:128-129
         return predicted_pose[:2, :2], predicted_pose[:2, 2]
+    if on_device:
+        k = int(rec[6])
+        best_angle = angles[k]
+        if int(rec[8]) > 0:                                                   # slam.py:157-159
+            best_angle = fine[k, int(rec[9])]
+        correction = np.degrees(best_angle - pred_theta)
+        if abs(correction) > 1.0 and VERBOSE:
+            print(f"  Submap rotation correction: {correction:+.1f}°")
+        ca, sa = np.cos(best_angle), np.sin(best_angle)
+        return np.array([[ca, -sa], [sa, ca]]), ref[:2].copy()
     src_d, tgt_d = ctx.filtered_clouds(ns, nt, rec)
     src = src_d.cpu().numpy()
     k = int(rec[6])

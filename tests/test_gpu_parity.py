@@ -1382,3 +1382,29 @@ def test_nn_batches_beyond_65535_pairs(uicp):
         do, io = oracle.nn(clouds[ps[b]], clouds[pt[b]])
         assert np.array_equal(i[b, :n], io) and np.array_equal(d[b, :n], do), b
         assert np.array_equal(i2[b, :n], io) and np.array_equal(d2[b, :n], do), b
+
+
+def test_submap_translation_refinement_on_the_device_and_on_the_host(uicp):
+    """slam.py:161-181 (the 80th-percentile inlier mean after the rotation sweeps) runs on the device for scans of at
+    most 2 048 raw rows and on the host, from the kernels' distances and indices, beyond: both equal the oracle's
+    restatement bit for bit — random poses, a scan with duplicated rows (ties in the percentile), very few inliers."""
+    from icpmi import submap, synth
+    submap.VERBOSE = False
+    sub = load_golden("submap_build")["out"]
+    segs = synth.maze_segments()
+    poses = synth.trajectory(40)
+    rng = np.random.default_rng(14)
+    for trial in range(6):
+        p = poses[int(rng.integers(5, 35))]
+        scan = synth.scan(p, 4000 + trial, segs=segs)
+        if trial == 3:
+            scan = np.vstack([scan, scan[::3]])[:2048]                                   # duplicates
+        if trial == 4:
+            scan = np.vstack([scan, synth.scan(p, 4100, segs=segs)])                       # 4 096 raw rows: the host path
+        th = p[2] + np.deg2rad(rng.uniform(-8, 8))
+        pred = np.array([[np.cos(th), -np.sin(th), p[0] + rng.uniform(-0.3, 0.3)], [np.sin(th), np.cos(th), p[1] + rng.uniform(-0.3, 0.3)],
+                         [0.0, 0.0, 1.0]])
+        kw = dict(angle_range=20.0, angle_step=2.0, fine_step=0.5, voxel_size=0.3 if trial != 5 else 2.5)
+        R, t = submap.submap_rotation_search(scan, sub, pred, **kw)
+        Ro, to = oracle.submap_rotation_search(scan, sub, pred, **kw)
+        assert np.array_equal(R, Ro) and np.array_equal(t, to), trial
