@@ -1408,3 +1408,23 @@ def test_submap_translation_refinement_on_the_device_and_on_the_host(uicp):
         R, t = submap.submap_rotation_search(scan, sub, pred, **kw)
         Ro, to = oracle.submap_rotation_search(scan, sub, pred, **kw)
         assert np.array_equal(R, Ro) and np.array_equal(t, to), trial
+
+
+def test_run_icp_pair_batch_with_pairs_beyond_the_capacity_hint(uicp):
+    """Pairs whose filtered clouds exceed the capacity hint of the batched search are searched and registered one by
+    one through the single-pair entries: the batch's results equal the per-pair chain for every pair."""
+    from icpmi import batch, prealign, synth
+    from utilities import features
+    srcs, tgts = synth.loop_closure_batch(6, seed0=300, shared_source=True)
+    kw = dict(error_threshold=1e-10, max_iterations=60, voxel_size=0.04, method="point_to_line", normal_k=12)
+    b = prealign.RunIcpPairBatch([srcs[0]] + tgts, np.zeros(6, dtype=np.int32), np.arange(1, 7, dtype=np.int32),
+                                 rotation_voxel_size=0.05, angle_step_coarse=4.0, angle_step_fine=0.5, max_rows_hint=256, **kw)
+    b.run()
+    R, t, err, info = b.unpack()
+    rec = b.search.records.cpu().numpy()
+    assert (rec[:6, 11] == 2).all()                                     # ~1 300 filtered rows > 256: nobody was searched on chip
+    features.VERBOSE = False
+    for i in range(6):
+        R0, t0, _ = features.rotation_search(srcs[0], tgts[i], 0.05, 4.0, 0.5)
+        Ri, ti, ei, ii = batch.icp_pair(srcs[0], tgts[i], R_init=R0, t_init=t0, **kw)
+        assert np.array_equal(R[i], Ri[0]) and np.array_equal(t[i], ti[0]) and err[i] == ei[0] and info["iters"][i] == ii["iters"][0], i

@@ -255,3 +255,44 @@ def test_bench_refuses_stale_pmc_traffic(tmp_path, monkeypatch):
     f.write_text(json.dumps(doc))
     t, why = bench.pmc_traffic("icp2_", 64)
     assert t is None and "stale" in why
+
+
+def test_arange_rows_is_numpys_arange():
+    """icpmi.prealign.arange_rows tabulates np.arange(lo[k], hi[k], step) for every k at once (the fine grids that can
+    follow each coarse winner of a rotation search, features.py:227-229): the same numbers and lengths bit for bit."""
+    from icpmi.prealign import arange_rows
+    for cstep, fstep in ((2.0, 0.2), (1.5, 0.1), (2.0, 0.5), (7.0, 0.33), (1.0, 2.5)):
+        coarse = np.deg2rad(np.arange(-180, 180, cstep))
+        lo, hi = coarse - np.deg2rad(cstep), coarse + np.deg2rad(cstep)
+        vals, n = arange_rows(lo, hi, np.deg2rad(fstep))
+        for k in range(len(coarse)):
+            ref = np.arange(lo[k], hi[k], np.deg2rad(fstep))
+            assert n[k] == len(ref) and np.array_equal(vals[k, :n[k]], ref), (cstep, fstep, k)
+    vals, n = arange_rows([1.0, 2.0], [1.0, 1.5], 0.1)                  # empty grids
+    assert list(n) == [0, 0]
+
+
+def test_candidate_poses_stay_out_of_obstacles():
+    """synth.loop_closure_batch: the defaults are unchanged by the rejection of poses inside boxes (none of them is
+    within reach at 0.6 m), the 3 m / 20 degree candidates all stand in free space."""
+    from icpmi import synth
+    rng_poses = []
+    for i in range(64):
+        rng = np.random.default_rng(500 + i)
+        d, a, th = rng.uniform(0.0, 0.6), rng.uniform(-np.pi, np.pi), np.deg2rad(rng.uniform(-6.0, 6.0))
+        rng_poses.append((0.5 + d * np.cos(a), -0.3 + d * np.sin(a)))
+    assert all(synth._free_pose(x, y) for x, y in rng_poses)            # first draws are always accepted at 0.6 m
+    assert not synth._free_pose(3.0, 2.0) and not synth._free_pose(9.9, 0.0) and synth._free_pose(0.5, -0.3)
+    srcs, tgts = synth.loop_closure_batch(3, seed0=500, shared_source=True, max_offset=3.0, max_yaw_deg=20.0)
+    assert srcs[0] is srcs[1] and all(len(t) == 2048 for t in tgts)     # a scan from free space sees a wall on every beam
+
+
+def test_pair_lists_of_the_batched_run_icp_pair():
+    from icpmi.prealign import _pair_lists
+    a, b, c = np.zeros((5, 2)), np.ones((6, 2)), np.ones((7, 2))
+    clouds, ps, pt = _pair_lists(a, [b, c])                              # one source shared by every pair (slam.py:576-579)
+    assert len(clouds) == 3 and list(ps) == [0, 0] and list(pt) == [1, 2]
+    clouds, ps, pt = _pair_lists([a, b], [b, c])
+    assert len(clouds) == 4 and list(ps) == [0, 1] and list(pt) == [2, 3]
+    with pytest.raises(ValueError):
+        _pair_lists([a], [b, c])
