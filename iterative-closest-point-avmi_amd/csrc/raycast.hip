@@ -943,7 +943,9 @@ extern "C" int icpmi_grid_update_scans_box(float* log_odds, void* counts_ws, int
         while (hit_off_host[s1 + 1] == hit_off_host[s1]) ++s1;
         const int nb1 = hit_off_host[s1 + 1] - hit_off_host[s1];
         const long long tx = (wx1 - wx0 + RT_TILE - 1) / RT_TILE, ty = (wy1 - wy0 + RT_TILE - 1) / RT_TILE;
-        if (nb1 > 0 && nb1 <= 65535 && tx * ty <= 4096) {
+        // (every workgroup looks at every beam: beyond a few hundred tiles — a box far larger than a lidar's reach — the two
+        // passes with counters are the cheaper way)
+        if (nb1 > 0 && nb1 <= 65535 && tx * ty <= 320) {
             ray_owner_kernel<<<RO_NEAR + (int)(tx * ty) * (RT_TILE / RO_FAR) * (RT_TILE / RO_FAR), RO_THREADS, 0, st>>>(g, origins + 2 * (size_t)s1, hits + 2 * (size_t)hit_off_host[s1], nb1,
                                                                                fin, (int)tx, (int)ty, (unsigned long long*)counts_ws);
             ICPMI_LAUNCH_CHECK();
