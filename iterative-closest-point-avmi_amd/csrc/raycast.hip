@@ -69,6 +69,10 @@ __device__ __forceinline__ bool world_to_cell_fast(double w, double mn, double r
     return true;
 }
 
+__device__ __forceinline__ bool world_to_cell_q(double w, double mn, double res, int& out) {   // same index, the division only near an integer
+    return world_to_cell_fast(w, mn, res, 1.0 / res, out);
+}
+
 // Walker over the cells of one ray.
 struct Ray {
     int m0, n0, sm, sn;       // start on major / minor axis, step signs
@@ -149,8 +153,8 @@ __device__ __forceinline__ void ray_count_body(
     const bool oky = world_to_cell(origin[1], g.min_y, g.res, oy);
     bool valid = okx && oky && beam < nb;
     if (valid) {
-        const bool a = world_to_cell(hits[2 * (size_t)beam], g.min_x, g.res, hx);
-        const bool b = world_to_cell(hits[2 * (size_t)beam + 1], g.min_y, g.res, hy);
+        const bool a = world_to_cell_q(hits[2 * (size_t)beam], g.min_x, g.res, hx);
+        const bool b = world_to_cell_q(hits[2 * (size_t)beam + 1], g.min_y, g.res, hy);
         valid = a && b;
     }
 
@@ -415,7 +419,7 @@ __device__ __forceinline__ void ray_scan_boxes_body(const GridDesc& g, const dou
         const int i = base + tid;
         uint32_t a = 0, b = 0, c = 0, d = 0;
         int hx = 0, hy = 0;
-        if (i < nb && world_to_cell(h[2 * (size_t)i], g.min_x, g.res, hx) && world_to_cell(h[2 * (size_t)i + 1], g.min_y, g.res, hy)) {
+        if (i < nb && world_to_cell_q(h[2 * (size_t)i], g.min_x, g.res, hx) && world_to_cell_q(h[2 * (size_t)i + 1], g.min_y, g.res, hy)) {
             const int bx0 = max(g.wx0, min(ox, hx)), bx1 = min(g.wx1 - 1, max(ox, hx));
             const int by0 = max(g.wy0, min(oy, hy)), by1 = min(g.wy1 - 1, max(oy, hy));
             if (bx0 <= bx1 && by0 <= by1) { a = (uint32_t)(g.nx - bx0); b = (uint32_t)(g.ny - by0); c = (uint32_t)(bx1 + 1); d = (uint32_t)(by1 + 1); }
@@ -513,7 +517,7 @@ __device__ __forceinline__ void ray_tile_body(const GridDesc& g, const double* _
         const int i = base + tid;
         int hx = 0, hy = 0, klo = 0, khi = 0;
         bool hit_in = false;
-        if (i < b1 && world_to_cell(h[2 * (size_t)i], g.min_x, g.res, hx) && world_to_cell(h[2 * (size_t)i + 1], g.min_y, g.res, hy)) {
+        if (i < b1 && world_to_cell_q(h[2 * (size_t)i], g.min_x, g.res, hx) && world_to_cell_q(h[2 * (size_t)i + 1], g.min_y, g.res, hy)) {
             hit_in = hx >= x0 && hx < x1 && hy >= y0 && hy < y1;
             // Bresenham stays inside the rectangle of its end points ...
             bool cross = !(max(ox, hx) < x0 || min(ox, hx) >= x1 || max(oy, hy) < y0 || min(oy, hy) >= y1);
