@@ -74,7 +74,16 @@ struct Icp2Args {
     int st_stride;
     int32_t* wide_list;       // pairs the first launch leaves to the wider shape (when the caller gave a workspace): the second
     int32_t* wide_count;      // launch walks this list instead of starting a workgroup per pair of the batch just to look
+    // Pairs that start FAR from their target (a candidate whose pre-alignment is wrong: every row metres from the nearest
+    // wall) walk most of the sorted target in every search.  A first launch that finds the mean squared nearest-neighbour
+    // distance of iteration 0 above far_d2 parks the pair after that iteration (same state as above) on far_list, and
+    // icp2_far_kernel continues it with searches that give up long walks for a scan over block boxes (sweep.hpp).  Same
+    // matches, same arithmetic: the pair's result does not depend on which kernel finished it.
+    int32_t* far_list;        // nullptr: never
+    int32_t* far_count;
+    double far_d2;            // +inf: never
 };
+constexpr int ICP2_FAR_THREADS = 1024, ICP2_FAR_SMAX = 2, ICP2_FAR_POINTS = 2048;   // the continuation's shape: most source rows, target points
 constexpr int ICP2_ST_PARKED = 100;     // internal status between the two stages
 
 // ── workgroup sums of NV values per thread ───────────────────────────────────────────────────────────
@@ -195,7 +204,7 @@ __device__ __forceinline__ void accumulate_step(double* ctrl, const double (&r)[
     ctrl[CTRL_TT] = (tt0 * r[0] + tt1 * r[1]) + t[0]; ctrl[CTRL_TT + 1] = (tt0 * r[2] + tt1 * r[3]) + t[1];
 }
 
-template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT, bool RESUME>
+template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT, bool RESUME, bool FAR = false>
 __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     __shared__ double redA[red_doubles<11>()];         // normal equations (10) / centroid sums (5) + carried squared error
@@ -230,6 +239,8 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
     const double2* snrm = TGT_LDS ? lds_nrm : a.g_snrm + a.off[tc];
     const int32_t* sorig = TGT_LDS ? lds_orig : a.g_sorig + a.off[tc];
     static_assert(TGT_LDS || !FILT, "the filter images live in LDS");
+    static_assert(!FAR || (FILT && RESUME), "the far continuation: filter images, parked state");
+    float4* lds_box = reinterpret_cast<float4*>(dyn + (size_t)a.lds_points * 48 + 32);     // FAR: boxes of blocks of 16 images
     __shared__ int rt_bits;                                      // max(|x - ox|, |y - oy|) over the target, float32 bits
     if (FILT && tid == 0) rt_bits = 0;
 
@@ -331,6 +342,10 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
         const double max_corr_sq = wave_uniform(a.max_corr_dist * a.max_corr_dist);   // icp.py:169
         const int need = max(3, N / 10);                                 // icp.py:186
         __syncthreads();
+        if constexpr (FAR) {
+            sweepf_build_boxes(lds_sq, M, lds_box, tid, THREADS);
+            __syncthreads();
+        }
         // largest |projection| of the target (the copy is sorted along it): rounding slack of the diagonal axes
         const double2 c_lo = sxy[0], c_hi = sxy[M - 1];
         const double uabs = wave_uniform(fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y))));
@@ -355,6 +370,11 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
             }
         }
         bool stopped = false;
+        // iteration 0 of a first launch: is this pair one for the far continuation?  (sum = the squared nearest-neighbour
+        // distances of all rows; the continuation runs iterations 1 .. max_iterations - 1)
+        const auto far_start = [&](int it, double sum) {
+            return !RESUME && it == 0 && sum > a.far_d2 * (double)N && N <= ICP2_FAR_THREADS * ICP2_FAR_SMAX && M <= ICP2_FAR_POINTS;
+        };
 #ifdef ICPMI_DIAG
         double dg_nn = 0, dg_red = 0, dg_lead = 0, dg_apply = 0;
 #endif
@@ -372,7 +392,30 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 // (Tried in round 3: testing delta + dq < d3 with the CURRENT distance dq to the better kept candidate — about
                 // twice as generous, 0.7 % instead of 2 % of the rows of a limit cycle search — costs 8 registers (a spill at
                 // six waves per SIMD) and the distances of the rows that then search after all: no faster, 5.11 against 5.07 ms.)
-                const bool within = valid && (fabs(px[s] - (double)ax[s]) + fabs(py[s] - (double)ay[s])) * 1.000000001 < (double)budget[s];
+                bool within;
+                if constexpr (FAR) {
+                    // The far continuation (a search costs ten times the usual) keeps d3 itself — lowered by the same
+                    // margins — instead of the budget, and tests with the row's CURRENT distance dq to the better of its
+                    // two candidates: every other target point was at least d3 from the anchor, so it is at least
+                    // d3 - delta from the row now; dq < d3 - delta keeps the match.  About twice as generous as
+                    // delta < (d3 - d1) / 2; both distances are evaluated for every row (they are cheap here).
+                    within = false;
+                    if (valid && budget[s] > 0.0f) {
+                        const int pa = pos[s], pb = pos2[s] >= 0 ? pos2[s] : pos[s];
+                        const double2 c = sxy[pa], e = sxy[pb];
+                        const double dx = px[s] - c.x, dy = py[s] - c.y;
+                        const double ex = px[s] - e.x, ey = py[s] - e.y;
+                        double q2 = 0.0, w2 = 0.0;
+                        q2 += dx * dx;
+                        q2 += dy * dy;
+                        w2 += ex * ex;
+                        w2 += ey * ey;
+                        const double g = (double)budget[s] - (fabs(px[s] - (double)ax[s]) + fabs(py[s] - (double)ay[s])) * 1.000000001;
+                        within = g > 0.0 && fmin(q2, w2) * 1.000000000001 < g * g * 0.999999999999;
+                    }
+                } else {
+                    within = valid && (fabs(px[s] - (double)ax[s]) + fabs(py[s] - (double)ay[s])) * 1.000000001 < (double)budget[s];
+                }
                 srch[s] = valid && !within;
                 if (within) {
                     // straight-line: a missing second candidate stands in as the first (never better), and only an
@@ -412,12 +455,25 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 for (int s = 0; s < ICP2_SMAX; ++s)
                     if (srch[s]) {
                         Top2 t2;
-                        if constexpr (FILT) t2 = sweepf_top2(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], centred);
+                        // (Tried: the searching rows of the far continuation queued in LDS and worked off by the lanes in order — a
+                        // quarter of the rows searching is then a quarter of the waves, once, instead of every wave twice.  Slower,
+                        // 7.8 against 6.4 ms on the 3 m / 20 degree candidates: the lanes of a wave then hold rows from all over the
+                        // scan, their block masks differ more, and a wave's far scan is bound by its own dependent chain, not by
+                        // the issue slots it shares.)
+                        if constexpr (FAR) {
+#ifdef ICPMI_DIAG
+                            t2 = sweepf_top2_far(lds_sq, sxy, lds_box, filt, M, dir, uabs, px[s], py[s], pos[s], &res[11]);
+#else
+                            t2 = sweepf_top2_far(lds_sq, sxy, lds_box, filt, M, dir, uabs, px[s], py[s], pos[s]);
+#endif
+                        }
+                        else if constexpr (FILT) t2 = sweepf_top2(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], centred);
                         else t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], centred);
                         pos[s] = t2.p1; pos2[s] = t2.p2;
                         const double d1 = sqrt(t2.s1), d3 = sqrt(t2.s3);
                         // minus the rounding of the single-precision anchor; rounded down
-                        const double bud = (d3 - d1) * 0.4999999995 - 1e-13 * (d3 + d1) - 1.3e-7 * (fabs(px[s]) + fabs(py[s]));
+                        const double bud = FAR ? d3 - 1e-13 * (d3 + d1) - 1.3e-7 * (fabs(px[s]) + fabs(py[s]))      // (see the test above)
+                                               : (d3 - d1) * 0.4999999995 - 1e-13 * (d3 + d1) - 1.3e-7 * (fabs(px[s]) + fabs(py[s]));
                         float bf = (float)bud;
                         bf = bf - fabsf(bf) * 1e-6f;
                         budget[s] = t2.s3 < __builtin_inf() ? bf : __builtin_inff();
@@ -447,6 +503,7 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                     if (!in[s]) continue;
                     const double2 q = sxy[pos[s]], nm = snrm[pos[s]];
                     const double dx = px[s] - q.x, dy = py[s] - q.y;
+                    if (!RESUME && it == 0) acc[10] += dx * dx + dy * dy;   // (finish_step ignores the error slot at iteration 0: it carries this sum to the far test)
                     if (has_corr) {                                   // the search's squared distance, recomputed bit for bit
                         double s2 = 0.0;
                         s2 += dx * dx;
@@ -461,13 +518,14 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                     acc[6] += c * bi;      acc[7] += nm.x * bi;   acc[8] += nm.y * bi;
                     acc[9] += 1.0;
                 }
-                acc[10] = e_part;
+                acc[10] += e_part;
                 wave_totals<11>(redA, acc);
                 __syncthreads();
                 DIAG_SET(c2);
                 if (lead) {
                     combine_totals<11>(redA, NWAVES, acc);
                     const bool stop = finish_step(ctrl, it, acc[10], acc[9], N, has_corr, need, a.error_threshold, tid == 0);
+                    if (tid == 0) ctrl[CTRL_STOP] = stop ? 1.0 : (far_start(it, acc[10]) ? 2.0 : 0.0);     // (before the solve: acc[10] dies here)
                     if (!stop) {
                         double A[3][3] = {{acc[0], acc[1], acc[2]}, {acc[1], acc[3], acc[4]}, {acc[2], acc[4], acc[5]}};
                         double rhs[3] = {acc[6], acc[7], acc[8]}, x[3];
@@ -486,7 +544,6 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                             ctrl[CTRL_T] = t[0]; ctrl[CTRL_T + 1] = t[1];
                         }
                     }
-                    if (tid == 0) ctrl[CTRL_STOP] = stop ? 1.0 : 0.0;
                 }
                 __syncthreads();
             } else {
@@ -496,6 +553,7 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 for (int s = 0; s < ICP2_SMAX; ++s) {
                     if (!in[s]) continue;
                     const double2 q = sxy[pos[s]];
+                    if (!RESUME && it == 0) { const double dx = px[s] - q.x, dy = py[s] - q.y; m[5] += dx * dx + dy * dy; }
                     if (has_corr) {                                   // the search's squared distance, recomputed bit for bit
                         const double dx = px[s] - q.x, dy = py[s] - q.y;
                         double s2 = 0.0;
@@ -507,7 +565,7 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                     }
                     m[0] += px[s]; m[1] += py[s]; m[2] += q.x; m[3] += q.y; m[4] += 1.0;
                 }
-                m[5] = e_part;
+                m[5] += e_part;
                 wave_totals<6>(redA, m);
                 __syncthreads();
                 DIAG_SET(c2);
@@ -515,13 +573,13 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                     combine_totals<6>(redA, NWAVES, m);
                     const bool stop = finish_step(ctrl, it, m[5], m[4], N, has_corr, need, a.error_threshold, tid == 0);
                     if (tid == 0) {
-                        ctrl[CTRL_STOP] = stop ? 1.0 : 0.0;
+                        ctrl[CTRL_STOP] = stop ? 1.0 : (far_start(it, m[5]) ? 2.0 : 0.0);
                         ctrl[CTRL_MP] = m[0] / m[4]; ctrl[CTRL_MP + 1] = m[1] / m[4];
                         ctrl[CTRL_MQ] = m[2] / m[4]; ctrl[CTRL_MQ + 1] = m[3] / m[4];
                     }
                 }
                 __syncthreads();
-                if (ctrl[CTRL_STOP] != 0.0) { stopped = true; break; }
+                if (ctrl[CTRL_STOP] == 1.0) { stopped = true; break; }
                 const double mpx = ctrl[CTRL_MP], mpy = ctrl[CTRL_MP + 1], mqx = ctrl[CTRL_MQ], mqy = ctrl[CTRL_MQ + 1];
                 // centred cross-covariance, icp.py:199-201
                 double W[4] = {0, 0, 0, 0};
@@ -551,7 +609,7 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 __syncthreads();
             }
             DIAG_T(c3);
-            if (ctrl[CTRL_STOP] != 0.0) { stopped = true; break; }
+            if (ctrl[CTRL_STOP] == 1.0) { stopped = true; break; }
             // ── apply to ALL rows; squared residual against this search's matches, icp.py:212-215 ─
             const double r0 = ctrl[CTRL_R], r1 = ctrl[CTRL_R + 1], r2 = ctrl[CTRL_R + 2], r3 = ctrl[CTRL_R + 3];
             const double t0 = ctrl[CTRL_T], t1 = ctrl[CTRL_T + 1];
@@ -570,13 +628,15 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 se += ey * ey;
                 e_part += se;
             }
+            if (!RESUME && it == 0 && ctrl[CTRL_STOP] == 2.0) break;
             DIAG_T(c4);
 #ifdef ICPMI_DIAG
             DIAG_ADD(dg_nn, c0, c1); DIAG_ADD(dg_red, c1, c2); DIAG_ADD(dg_lead, c2, c3); DIAG_ADD(dg_apply, c3, c4);
             if (tid == 0) { res[4] = dg_nn; res[5] = dg_red; res[6] = dg_lead; res[7] = dg_apply; }
 #endif
         }
-        if (!RESUME && !stopped && it_end < a.max_iterations) {
+        const bool far_parked = !RESUME && !stopped && ctrl[CTRL_STOP] == 2.0;      // left after iteration 0
+        if (!RESUME && !stopped && (far_parked || it_end < a.max_iterations)) {
             // parked for the second stage: rows and matches as they are, totals through the result record
 #pragma unroll
             for (int s = 0; s < ICP2_SMAX; ++s) {
@@ -588,7 +648,8 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
             }
             if (tid == 0) {
                 ctrl[CTRL_STATUS] = (double)ICP2_ST_PARKED;
-                a.list[atomicAdd(a.list_count, 1)] = b;
+                if (far_parked) a.far_list[atomicAdd(a.far_count, 1)] = b;
+                else a.list[atomicAdd(a.list_count, 1)] = b;
             }
         } else if (!stopped && a.max_iterations > 0) {
             // the last step's error has not been reduced yet: icp.py:215-223 for it = max_iterations - 1
@@ -657,6 +718,15 @@ __global__ __launch_bounds__(THREADS, THREADS == 768 ? 6 : 4) void icp2_resume_r
     }
 }
 
+// continuation of the pairs found far from their target (Icp2Args::far_list): one shape for all of them
+__global__ __launch_bounds__(ICP2_FAR_THREADS, 4) void icp2_far_kernel(Icp2Args a) {
+    const int count = *a.far_count;
+    for (int j = blockIdx.x; j < count; j += gridDim.x) {
+        icp2_pair<ICP2_FAR_THREADS, ICP2_FAR_SMAX, true, true, true, true>(a, __builtin_amdgcn_readfirstlane(a.far_list[j]));
+        __syncthreads();                                    // LDS is staged again for the next pair
+    }
+}
+
 // host side: called by icpmi_icp_batch (icp.hip) when a prepared buffer is given and everything fits
 int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const int32_t* ps, const int32_t* pt,
                 int n_pairs, int max_src_n, int max_tgt_n, int total_rows, const icpmi_icp_params* p, const double* init,
@@ -665,6 +735,7 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     a.it_begin = 0; a.it_limit = 0x7fffffff; a.resume = 0;
     a.st_xy = nullptr; a.st_pos = nullptr; a.list = nullptr; a.list_count = nullptr; a.st_stride = 0;
     a.wide_list = nullptr; a.wide_count = nullptr;
+    a.far_list = nullptr; a.far_count = nullptr; a.far_d2 = __builtin_inf();
     const unsigned char* b = (const unsigned char*)prepared;
     a.pts = pts; a.off = off; a.cnt = cnt; a.pair_src = ps; a.pair_tgt = pt; a.init = init; a.results = results;
     a.g_sxy = (const double2*)b;
@@ -746,7 +817,7 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     constexpr int STAGE1_ITERATIONS = 12;                   // measured 6.12 / 5.42 / 5.36 / 5.38 / 5.39 ms at 8 / 10 / 12 / 14 / 16
     const char* senv = option("ICP2_STAGES");
     const size_t st_rows = (size_t)n_pairs * (size_t)max_src_n;
-    const size_t st_bytes = st_rows * 20 + (size_t)n_pairs * 8 + 64;
+    const size_t st_bytes = st_rows * 20 + (size_t)n_pairs * 12 + 64;
     // point-to-line only: its pairs either settle within ~10 iterations or circle to the limit; point-to-point pairs all
     // take 25-40 and would all be parked (ICP2_STAGES = 2 forces the stages for them too: tests)
     const bool have_ws = workspace && workspace_bytes >= st_bytes;
@@ -757,17 +828,26 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     const int stage2_grid = n_pairs / 8 > 256 ? n_pairs / 8 : 256;
     // the launch for wide clouds: a thirty-second (a launch of 4 096 workgroups that find an empty list still takes 100 us)
     const int wide_grid = n_pairs < 256 ? n_pairs : (n_pairs / 32 > 256 ? n_pairs / 32 : 256);
-    if (have_ws && (two_stage || T2)) {
+    // option ICP2_FAR = the mean squared distance (m^2) of iteration 0 above which a pair goes to the far continuation
+    // (default 0.5: 0.7 m rms — the candidates ICP converges from by itself stay below it; 0 = never)
+    double far_d2 = 0.5;
+    if (const char* e = option("ICP2_FAR")) far_d2 = atof(e);
+    const bool far_ok = have_ws && in_lds && want_filter && far_d2 > 0.0 && p->max_iterations > 1;
+    if (have_ws && (two_stage || T2 || far_ok)) {
         unsigned char* w = (unsigned char*)workspace;
         a.st_xy = (double2*)w;
         a.st_pos = (int32_t*)(w + st_rows * 16);
         a.list = (int32_t*)(w + st_rows * 20);
         a.wide_list = a.list + n_pairs;
-        a.list_count = a.wide_list + n_pairs;
+        a.far_list = a.wide_list + n_pairs;
+        a.list_count = a.far_list + n_pairs;
         a.wide_count = a.list_count + 1;
+        a.far_count = a.list_count + 2;
         a.st_stride = max_src_n;
         if (!T2) { a.wide_list = nullptr; a.wide_count = nullptr; }
-        if (hipMemsetAsync(a.list_count, 0, 2 * sizeof(int32_t), st) != hipSuccess) return ICPMI_ERR_HIP;
+        if (far_ok) a.far_d2 = far_d2;
+        else { a.far_list = nullptr; a.far_count = nullptr; }
+        if (hipMemsetAsync(a.list_count, 0, 3 * sizeof(int32_t), st) != hipSuccess) return ICPMI_ERR_HIP;
     }
     // The launch for wide clouds (a handful of pairs, ~0.1 ms at a few per cent of the chip) only needs the first stage's
     // list: it runs on a side stream beside the second stage and joins the caller's stream afterwards.
@@ -797,8 +877,27 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     }
 #undef ICPMI_ICP2_GO
 #undef ICPMI_ICP2_GO2
+    if (a.far_list) {                                       // after every first launch (the wide one has joined the stream)
+        Icp2Args c = a;
+        c.resume = 1; c.it_begin = 1; c.it_limit = 0x7fffffff; c.skip_over = 0; c.n_lo = -1; c.m_lo = 0;
+        int cap = 64;
+        while (cap < max_tgt_n && cap < ICP2_FAR_POINTS) cap <<= 1;
+        c.lds_points = cap;
+        const size_t lds = (size_t)cap * 49 + 32;           // the filter layout + 16 B per block of 16 images
+        if (hipFuncSetAttribute((const void*)icp2_far_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return ICPMI_ERR_HIP;
+        icp2_far_kernel<<<n_pairs < 256 ? n_pairs : 256, ICP2_FAR_THREADS, lds, st>>>(c);
+    }
     ICPMI_LAUNCH_CHECK();
     return ICPMI_OK;
 }
 
 }  // namespace icpmi
+
+#ifdef ICPMI_DIAG
+extern "C" int icpmi_diag_read(unsigned long long* out16) {   // diagnostic build only: read and clear the phase counters of sweep.hpp
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(icpmi::icpmi_dbg), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(icpmi::icpmi_dbg), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -21,7 +21,7 @@
 
 namespace icpmi {
 
-static const char* const kOptionNames[] = {"ICP2_SIDE", "ICP2_SHAPE", "ICP2_FILTER", "ICP2_STAGES", "POLAR", "PREP_KNN", "RAYCAST",
+static const char* const kOptionNames[] = {"ICP2_SIDE", "ICP2_FAR", "ICP2_SHAPE", "ICP2_FILTER", "ICP2_STAGES", "POLAR", "PREP_KNN", "RAYCAST",
                                            "RT_WGS", "RS_BATCH"};
 
 struct Options {

@@ -666,30 +666,111 @@ __device__ __forceinline__ void sweepf_build_boxes(const float4* sq, int m, floa
     }
 }
 
-// float32 lower bound of the filter value (SweepFRound: fma(dx, dx, dy * dy)) of any image inside the box
-__device__ __forceinline__ float sweepf_box_s2(const float4 bb, float qx, float qy) {
-    const float dx = fmaxf(fmaxf(bb.x - qx, qx - bb.z), 0.0f), dy = fmaxf(fmaxf(bb.y - qy, qy - bb.w), 0.0f);
-    return __builtin_fmaf(dx, dx, dy * dy);
+#ifdef ICPMI_DIAG
+static __device__ unsigned long long icpmi_dbg[16];      // diagnostic build: cycles of the phases of sweepf_top2_far (per lane-call, summed)
+#define DBG_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define DBG_ADD(k, a, b) atomicAdd(&icpmi_dbg[k], (b) - (a))
+#else
+#define DBG_T(v)
+#define DBG_ADD(k, a, b)
+#endif
+// One pass over the boxes of a far query.  Per box, with the very operations of the point filter (monotone roundings):
+//   lo = the filter value no image inside the box can undercut (nearest point of the box),
+//   hi = the filter value no image inside the box can exceed   (farthest corner).
+// A block that holds at least `need` points puts the query's need-th nearest point within its farthest corner, so the
+// smallest hi seen so far bounds the search before a single point has been looked at: as a filter threshold
+//   Tc = 1.001 hi_min + 1e5 e15^2
+// (>= the threshold SweepFQuery::bounds derives from the exact bound ((sqrt(hi_min) (1 + 1e-5) + 2 e15)^2: the images are
+// within e15 of the exact offsets; (a + b)^2 <= (1 + d) a^2 + (1 + 1/d) b^2 with d = 1e-4).  Blocks whose lo is within
+// the running threshold are noted in a bit mask — the loop over boxes is uniform across the wave; each lane then walks
+// its OWN bits (the lanes hold different queries: a loop that scanned every block somebody needs would run over all of
+// them — measured: two blocks per query and still the time of a full scan) and tests a block again before scanning it.
+// offer(i) is called for the points within the threshold and keeps T, the threshold of what the caller has found.
+template <class Offer>
+__device__ __forceinline__ void sweepf_far_scan(const float4* sq, const float4* sbox, int m, const SweepFQuery& fq, int need,
+                                                const float& T, Offer offer) {
+    const int n_blocks = (m + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
+    const int n_bound = (m - need + SWEEP_BLOCK) / SWEEP_BLOCK;        // blocks 0 .. n_bound-1 hold at least `need` points
+    const float kabs = 1e5f * fq.e15 * fq.e15;
+    float Tc = __builtin_inff();
+    // the points of block b against the filter, eight image loads in flight (the image copy is padded to whole blocks;
+    // entries past m are never offered)
+    const auto scan_block = [&](int b) {
+#pragma unroll
+        for (int e = 0; e < SWEEP_BLOCK / 8; ++e) {
+            const int i0 = b * SWEEP_BLOCK + e * 8;
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float2 c = *reinterpret_cast<const float2*>(sq + i0 + k);
+                const float ex = fq.x - c.x, ey = fq.y - c.y;
+                v[k] = __builtin_fmaf(ex, ex, ey * ey);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (!(v[k] > fminf(T, Tc)) && i0 + k < m) offer(i0 + k);
+        }
+    };
+    for (int g0 = 0; g0 < n_blocks; g0 += 128) {                       // (one group up to 2 048 points)
+        unsigned long long mask[2] = {0, 0};
+        float lo_min = __builtin_inff();
+        int b_min = g0;
+        DBG_T(e0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int nb = min(64, n_blocks - g0 - 64 * h);
+#pragma unroll 8
+            for (int j = 0; j < nb; ++j) {                             // (unrolled: eight box loads in flight, not one LDS latency per box)
+                const int b = g0 + 64 * h + j;
+                const float4 bb = sbox[b];
+                const float ax = bb.x - fq.x, bx = fq.x - bb.z, ay = bb.y - fq.y, by = fq.y - bb.w;
+                const float lx = fmaxf(fmaxf(ax, bx), 0.0f), ly = fmaxf(fmaxf(ay, by), 0.0f);
+                const float hx = fmaxf(-ax, -bx), hy = fmaxf(-ay, -by);
+                const float lo = __builtin_fmaf(lx, lx, ly * ly);
+                const float hi = __builtin_fmaf(hx, hx, hy * hy);
+                if (b < n_bound) Tc = fminf(Tc, __builtin_fmaf(hi, 1.001f, kabs));      // NaN: fminf keeps Tc
+                mask[h] |= (unsigned long long)(lo > fminf(T, Tc) ? 0 : 1) << j;        // NaN compares false: scanned
+                b_min = lo < lo_min ? b : b_min;
+                lo_min = fminf(lo_min, lo);
+            }
+        }
+        // the nearest box first (every lane at once): what it holds tightens the threshold for all the others
+        {
+            const unsigned long long bit = 1ull << ((b_min - g0) & 63);
+            const bool upper = b_min - g0 >= 64;
+            const bool set = ((upper ? mask[1] : mask[0]) & bit) != 0;
+            mask[0] &= upper ? ~0ull : ~bit;
+            mask[1] &= upper ? ~bit : ~0ull;
+            if (set) scan_block(b_min);
+        }
+        DBG_T(e1);
+        DBG_ADD(2, e0, e1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned long long mk = mask[h];
+            while (mk) {
+                const int b = g0 + 64 * h + __builtin_ctzll(mk);
+                mk &= mk - 1;
+                const float4 bb = sbox[b];
+                const float lx = fmaxf(fmaxf(bb.x - fq.x, fq.x - bb.z), 0.0f), ly = fmaxf(fmaxf(bb.y - fq.y, fq.y - bb.w), 0.0f);
+                if (__builtin_fmaf(lx, lx, ly * ly) > fminf(T, Tc)) continue;
+                scan_block(b);
+            }
+        }
+    }
 }
 
 // finish a 1-NN search over all blocks (best / bpos: what the walk has found so far)
 __device__ __forceinline__ void sweepf_far_nn(const float4* sq, const double2* sxy, const float4* sbox, const SweepFQuery& fq, int m,
                                               double qx, double qy, double& best, int& bpos, float& T) {
     float W;
-    for (int b = 0; b * SWEEP_BLOCK < m; ++b) {
-        if (sweepf_box_s2(sbox[b], fq.x, fq.y) > T) continue;          // NaN compares false: the block is scanned
-        const int i1 = min(m, (b + 1) * SWEEP_BLOCK);
-        for (int i = b * SWEEP_BLOCK; i < i1; ++i) {
-            const float4 c = sq[i];
-            const float ex = fq.x - c.x, ey = fq.y - c.y;
-            if (__builtin_fmaf(ex, ex, ey * ey) > T) continue;
-            const double s = sweep_d2(qx, qy, sxy[i]);
-            if (s == best && i != bpos) {                              // exact tie: the lowest original row wins
-                if (sweepf_row(c) < sweepf_row(sq[bpos])) bpos = i;
-            }
-            if (s < best) { best = s; bpos = i; fq.bounds(best, W, T); }
+    sweepf_far_scan(sq, sbox, m, fq, 1, T, [&](int i) {
+        const double s = sweep_d2(qx, qy, sxy[i]);
+        if (s == best && i != bpos) {                                  // exact tie: the lowest original row wins
+            if (sweepf_row(sq[i]) < sweepf_row(sq[bpos])) bpos = i;
         }
-    }
+        if (s < best) { best = s; bpos = i; fq.bounds(best, W, T); }
+    });
 }
 
 // sweepf_nn for callers whose queries may lie far from the cloud (the rotation search: most angles put the source metres
@@ -734,6 +815,88 @@ __device__ __forceinline__ int sweepf_nn_far(const float4* sq, const double2* sx
     return bpos;
 }
 
+// sweepf_top2 for the same kind of query (the continuation kernel of pairs the fused ICP finds metres off their target,
+// icp2.hip): the walk, abandoned after SWEEP_FAR_ROUNDS rounds for the scan over block boxes with the third distance as
+// the bound.  The scan passes over the positions the walk has visited once more: the two kept positions are skipped by
+// index, any other revisited point is at least as far as the kept third distance and changes nothing.
+__device__ __forceinline__ void top2_offer(Top2& t, const float4* sq, double s, int i, int row) {
+    if (s == t.s1 || s == t.s2) {
+        // exact tie with a kept distance: order by original row (the rule everywhere: (distance, row) ascending)
+        const int r1 = sweepf_row(sq[t.p1]);
+        const int r2 = t.p2 >= 0 ? sweepf_row(sq[t.p2]) : 0x7fffffff;
+        if (s < t.s1 || (s == t.s1 && row < r1)) { t.s3 = t.s2; t.s2 = t.s1; t.p2 = t.p1; t.s1 = s; t.p1 = i; }
+        else if (s < t.s2 || row < r2) { t.s3 = t.s2; t.s2 = s; t.p2 = i; }
+        else t.s3 = s;                                             // tie with the second, lost on the row
+    } else {
+        const bool c1 = s < t.s1, c2 = s < t.s2, c3 = s < t.s3;
+        t.s3 = c2 ? t.s2 : (c3 ? s : t.s3);
+        t.s2 = c1 ? t.s1 : (c2 ? s : t.s2);
+        t.p2 = c1 ? t.p1 : (c2 ? i : t.p2);
+        t.s1 = c1 ? s : t.s1;
+        t.p1 = c1 ? i : t.p1;
+    }
+}
+
+#ifndef SWEEP_FAR_ROUNDS_TOP2
+#define SWEEP_FAR_ROUNDS_TOP2 12
 #endif
+#ifndef SWEEP_FAR_SEED_D2
+#define SWEEP_FAR_SEED_D2 0.25
+#endif
+__device__ __forceinline__ Top2 sweepf_top2_far(const float4* sq, const double2* sxy, const float4* sbox, const SweepF& f, int m, int dir,
+                                                double uabs, double qx, double qy, int seed, double* diag = nullptr) {
+    DBG_T(d0);
+    const SweepFQuery fq(f, dir, uabs, qx, qy);
+    Top2 t;
+    t.p1 = 0; t.p2 = -1;
+    t.s1 = t.s2 = t.s3 = __builtin_inf();
+    float W = __builtin_inff(), T = __builtin_inff();
+    const bool seeded = seed >= 0 && seed < m;
+    if (seeded) { t.s1 = sweep_d2(qx, qy, sxy[seed]); t.p1 = seed; }
+    const bool from_seed = seeded && !(fq.polar && fabsf(sq[seed].z - fq.u) > 3.0f);
+    const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
+    SweepFWalk w(from_seed ? seed - 1 : h0 - 1, h0, m, fq.u);
+    const int skip = seeded ? seed : -1;                               // the seed is in the list already
+    int rounds = 0;
+    // a row half a metre from its previous match is far from everything, as a rule: straight to the scan
+    bool far = seeded && t.s1 > SWEEP_FAR_SEED_D2;
+    DBG_T(d1);
+#pragma unroll 1
+    for (int pass = 0; pass < 2 && !far; ++pass) {
+        while (w.more()) {
+            if (++rounds > SWEEP_FAR_ROUNDS_TOP2) { far = true; break; }
+            const SweepFRound r(sq, w, fq, W, T);
+            const bool pr = r.pr && w.hi != skip, pl = r.pl && w.lo != skip;
+            if (pr || pl) {
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int i = side == 0 ? w.hi : w.lo;
+                    if (side == 0 ? pr : pl) top2_offer(t, sq, sweep_d2(qx, qy, sxy[i]), i, sweepf_row(side == 0 ? r.cr : r.cl));
+                }
+                fq.bounds(t.s3, W, T);
+            }
+            r.advance(w);
+        }
+        if (far || !fq.polar || !w.wrap(m)) break;
+    }
+    DBG_T(d2);
+    DBG_ADD(0, d0, d1); DBG_ADD(1, d1, d2); DBG_ADD(5, 0ull, 1ull);
+    if (far) {
+#ifdef ICPMI_DIAG
+        if (diag) atomicAdd(diag, 4294967296.0);
+#endif
+        sweepf_far_scan(sq, sbox, m, fq, 3, T, [&](int i) {
+            if (i == t.p2 || (i == t.p1 && t.s1 < __builtin_inf())) return;
+            top2_offer(t, sq, sweep_d2(qx, qy, sxy[i]), i, sweepf_row(sq[i]));
+            fq.bounds(t.s3, W, T);
+        });
+        DBG_T(d4);
+        DBG_ADD(3, d2, d4); DBG_ADD(6, 0ull, 1ull);
+    }
+    return t;
+}
+
+#endif
+
 
 }  // namespace icpmi

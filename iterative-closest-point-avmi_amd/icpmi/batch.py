@@ -248,11 +248,11 @@ class IcpBatch:
             self.prepared = torch.empty(L.icpmi_prepared_bytes(self.raw.total_rows, self.raw.n_clouds, self.max_tgt_n),
                                         dtype=torch.uint8, device=dev)
             self.tgt_ids_host = np.ascontiguousarray(self.tgt_ids, dtype=np.int32)
-            if self.B >= 1024:
-                # a large batch runs in two stages (csrc/icp2.hip): the pairs still running after 12 iterations are
-                # parked in this workspace and continued together by a second launch
-                self.icp_ws = torch.empty(L.icpmi_icp_workspace_bytes(self.B, self.max_src_n, self.dim),
-                                          dtype=torch.uint8, device=dev)
+            # parked pairs (csrc/icp2.hip): a large batch runs in two stages — the pairs still running after 12
+            # iterations are continued together by a second launch — and pairs that start metres from their target
+            # are continued by the kernel for far queries
+            self.icp_ws = torch.empty(L.icpmi_icp_workspace_bytes(self.B, self.max_src_n, self.dim),
+                                      dtype=torch.uint8, device=dev)
         else:
             if use_p2l:
                 self.normals = torch.zeros((max(self.raw.total_rows, 1), 2), dtype=torch.float64, device=dev)

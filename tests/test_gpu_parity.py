@@ -1410,6 +1410,48 @@ def test_submap_translation_refinement_on_the_device_and_on_the_host(uicp):
         assert np.array_equal(R, Ro) and np.array_equal(t, to), trial
 
 
+@pytest.mark.parametrize("method", ["point_to_line", "point_to_point"])
+def test_far_pairs_finish_on_the_far_continuation_with_the_same_bits(uicp, libopt, method):
+    """Pairs that start metres from their target leave the first launch after iteration 0 and are finished by
+    icp2_far_kernel (walks given up for the scan over block boxes).  Same matches, same arithmetic: every result equals the
+    one of the plain path (option ICP2_FAR = 0), whether the threshold sends the far pairs only (default) or every pair."""
+    from icpmi import batch, synth
+    B = 48
+    srcs, tgts = synth.loop_closure_batch(B, seed0=4100, shared_source=True, max_offset=3.0, max_yaw_deg=20.0)
+    out = {}
+    for far in ("0", None, "1e-12"):
+        libopt.setenv("ICP2_FAR", far) if far else libopt.delenv("ICP2_FAR")
+        R, t, err, info = batch.icp_batch(srcs[0], tgts, 1e-10, 60, 0.04, None, None, method, 12)
+        out[far] = (R, t, err, info["iters"], info["status"])
+    for far in (None, "1e-12"):
+        for a, b in zip(out["0"], out[far]):
+            assert np.array_equal(a, b), (far, method)
+    for i in range(0, B, 16):
+        Ro, to, eo, io = oracle.icp(srcs[0], tgts[i], 1e-10, 60, 0.04, method=method, normal_k=12)
+        assert int(out[None][3][i]) == io["iters"], i
+        if io["iters"] < 60:
+            assert rot_err(out[None][0][i], out[None][1][i], Ro, to) < FRO_TOL, i
+
+
+def test_far_continuation_beside_the_two_stages(uicp, libopt):
+    """A batch large enough for the two-stage run (>= 1 024 pairs) with far pairs in it: first stage, second stage and far
+    continuation together give the bits of the single plain launch."""
+    from icpmi import batch, synth
+    B = 1056
+    srcs, tgts = synth.loop_closure_batch(B, seed0=4300, shared_source=True, max_offset=2.0, max_yaw_deg=12.0)
+    srcs, tgts = [c[::4] for c in srcs], [c[::4] for c in tgts]            # 512 beams: a quick batch
+    out = {}
+    for far, stages in (("0", "1"), (None, None), ("0.04", None)):
+        libopt.setenv("ICP2_FAR", far) if far else libopt.delenv("ICP2_FAR")
+        libopt.setenv("ICP2_STAGES", stages) if stages else libopt.delenv("ICP2_STAGES")
+        R, t, err, info = batch.icp_batch(srcs[0], tgts, 1e-10, 40, 0.04, None, None, "point_to_line", 12)
+        out[(far, stages)] = (R, t, err, info["iters"], info["status"])
+    ref = out[("0", "1")]
+    for k in ((None, None), ("0.04", None)):
+        for a, b in zip(ref, out[k]):
+            assert np.array_equal(a, b), k
+
+
 def test_run_icp_pair_batch_with_pairs_beyond_the_capacity_hint(uicp):
     """Pairs whose filtered clouds exceed the capacity hint of the batched search are searched and registered one by
     one through the single-pair entries: the batch's results equal the per-pair chain for every pair."""
