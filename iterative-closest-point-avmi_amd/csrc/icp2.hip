@@ -240,7 +240,8 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
     const int32_t* sorig = TGT_LDS ? lds_orig : a.g_sorig + a.off[tc];
     static_assert(TGT_LDS || !FILT, "the filter images live in LDS");
     static_assert(!FAR || (FILT && RESUME), "the far continuation: filter images, parked state");
-    float4* lds_box = reinterpret_cast<float4*>(dyn + (size_t)a.lds_points * 48 + 32);     // FAR: boxes of blocks of 16 images
+    float4* lds_tree = reinterpret_cast<float4*>(dyn + (size_t)a.lds_points * 48 + 32);    // FAR: box hierarchy over blocks of 16 images (sweep.hpp)
+    const int tree_leaves = sweepf_tree_leaves(M);
     __shared__ int rt_bits;                                      // max(|x - ox|, |y - oy|) over the target, float32 bits
     if (FILT && tid == 0) rt_bits = 0;
 
@@ -343,7 +344,7 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
         const int need = max(3, N / 10);                                 // icp.py:186
         __syncthreads();
         if constexpr (FAR) {
-            sweepf_build_boxes(lds_sq, M, lds_box, tid, THREADS);
+            sweepf_build_tree(lds_sq, M, lds_tree, tree_leaves, tid, THREADS);
             __syncthreads();
         }
         // largest |projection| of the target (the copy is sorted along it): rounding slack of the diagonal axes
@@ -462,9 +463,9 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                         // the issue slots it shares.)
                         if constexpr (FAR) {
 #ifdef ICPMI_DIAG
-                            t2 = sweepf_top2_far(lds_sq, sxy, lds_box, filt, M, dir, uabs, px[s], py[s], pos[s], &res[11]);
+                            t2 = sweepf_top2_far(lds_sq, sxy, lds_tree, tree_leaves, filt, M, dir, uabs, px[s], py[s], pos[s], &res[11]);
 #else
-                            t2 = sweepf_top2_far(lds_sq, sxy, lds_box, filt, M, dir, uabs, px[s], py[s], pos[s]);
+                            t2 = sweepf_top2_far(lds_sq, sxy, lds_tree, tree_leaves, filt, M, dir, uabs, px[s], py[s], pos[s]);
 #endif
                         }
                         else if constexpr (FILT) t2 = sweepf_top2(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], centred);
@@ -883,7 +884,7 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
         int cap = 64;
         while (cap < max_tgt_n && cap < ICP2_FAR_POINTS) cap <<= 1;
         c.lds_points = cap;
-        const size_t lds = (size_t)cap * 49 + 32;           // the filter layout + 16 B per block of 16 images
+        const size_t lds = (size_t)cap * 48 + 32 + 32 * (size_t)sweepf_tree_leaves(cap);    // the filter layout + the box hierarchy
         if (hipFuncSetAttribute((const void*)icp2_far_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ICPMI_ERR_HIP;
         icp2_far_kernel<<<n_pairs < 256 ? n_pairs : 256, ICP2_FAR_THREADS, lds, st>>>(c);

@@ -365,7 +365,7 @@ typedef float rsb_v2f __attribute__((ext_vector_type(2)));
 // far exceeds it (then +inf returns: it cannot be the minimum).
 __device__ __forceinline__ double rsb_score_angle(const double2* src_c, int n, const float4* sq, const double2* sxy, const SweepF& filt,
                                                   int m, int dir, double uabs, double c, double s, double shx, double shy,
-                                                  const volatile double* limit, bool prune, const float4* sbox) {
+                                                  const volatile double* limit, bool prune, const float4* tree, int leaves) {
     double acc = 0.0;
     const int lane = lane_id();
     for (int first = 0; first < n; first += ICPMI_WAVE) {             // wave-uniform trip count
@@ -374,7 +374,7 @@ __device__ __forceinline__ double rsb_score_angle(const double2* src_c, int n, c
             const double2 p = src_c[i];
             const double qx = (p.x * c + p.y * -s) + shx, qy = (p.x * s + p.y * c) + shy;   // src_c @ R.T + mu_t, features.py:216
             double d2;
-            (void)sweepf_nn_far(sq, sxy, sbox, filt, m, dir, uabs, qx, qy, d2);
+            (void)sweepf_nn_far(sq, sxy, tree, leaves, filt, m, dir, uabs, qx, qy, d2);
             const double d = sqrt(d2);                                  // KDTree distance ...
             acc += d * d;                                               // ... squared, features.py:218
         }
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     double2* sxy = reinterpret_cast<double2*>(dyn);
     double2* src_c = reinterpret_cast<double2*>(dyn + (size_t)a.cap * 16);
     float4* sq = reinterpret_cast<float4*>(dyn + (size_t)a.cap * 32) + 1;      // one padding entry at either end
-    float4* sbox = reinterpret_cast<float4*>(dyn + (size_t)a.cap * 48 + 32);   // boxes of blocks of 16 sorted positions (sweep.hpp: far queries)
+    float4* tree = reinterpret_cast<float4*>(dyn + (size_t)a.cap * 48 + 32);   // box hierarchy over blocks of 16 sorted positions (sweep.hpp: far queries)
 
 #ifdef RSB_X_TIMES          // diagnostic build: cycles per phase in the record (tools/time_prealign.py RSB_TIMES=1)
 #define RSB_T(k) tph[k] = __builtin_readcyclecounter()
@@ -465,7 +465,8 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     __syncthreads();
     filt.rt = __int_as_float(rt_bits) * 1.000001f;
     filt.ut = fmaxf(fabsf(sq[0].z), fabsf(sq[m - 1].z)) * 1.000001f;
-    sweepf_build_boxes(sq, m, sbox, tid, RSB_THREADS);                 // visible after the barrier behind the field
+    const int leaves = sweepf_tree_leaves(m);
+    sweepf_build_tree(sq, m, tree, leaves, tid, RSB_THREADS);          // complete after the barrier behind the field
     const double2 c_lo = sxy[0], c_hi = sxy[m - 1];
     const double uabs = fmax(fabs(proj(dir, c_lo.x, c_lo.y)), fabs(proj(dir, c_hi.x, c_hi.y)));
 
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
         const int k = order[item];
         if ((double)lb[k] > *(volatile double*)&best_score) break;              // bounds ascend: nothing further on can win
         const double sc_k = rsb_score_angle(src_c, n, sq, sxy, filt, m, dir, uabs, a.coarse_cs[2 * k], a.coarse_cs[2 * k + 1], mutx, muty,
-                                            &best_score, prune, sbox);
+                                            &best_score, prune, tree, leaves);
         if (lane_id() == 0) {
             scores[k] = sc_k;
             atomicAdd(&n_evals, 1);
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     __syncthreads();
     const double* fcs = a.fine_cs + (size_t)kbest * a.max_fine * 2;
     for (int j = wave_id(); j < nf; j += RSB_WAVES) {
-        const double sc_j = rsb_score_angle(src_c, n, sq, sxy, filt, m, dir, uabs, fcs[2 * j], fcs[2 * j + 1], mutx, muty, &best_score, prune, sbox);
+        const double sc_j = rsb_score_angle(src_c, n, sq, sxy, filt, m, dir, uabs, fcs[2 * j], fcs[2 * j + 1], mutx, muty, &best_score, prune, tree, leaves);
         if (lane_id() == 0) {
             scores[j] = sc_j;
             atomicAdd(&n_evals, 1);
@@ -774,7 +775,7 @@ extern "C" int icpmi_rotation_search_batch(const double* pts, const int32_t* off
     a.cap = cap;
     const char* e = option("RS_BATCH");
     a.prune = e && e[0] == 'f' ? 0 : 1;                                 // "full": every angle scored exactly
-    const size_t lds = (size_t)cap * 49 + 32;
+    const size_t lds = (size_t)cap * 48 + 32 + 32 * (size_t)sweepf_tree_leaves(cap);
     if (hipFuncSetAttribute((const void*)rotation_search_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return ICPMI_ERR_HIP;
     rotation_search_batch_kernel<<<n_pairs, RSB_THREADS, lds, st>>>(a);

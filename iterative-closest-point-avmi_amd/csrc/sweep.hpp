@@ -637,35 +637,26 @@ __device__ __forceinline__ Top2 sweepf_top2(const float4* sq, const double2* sxy
     return t;
 }
 
-// ── far queries: boxes of blocks of the sort order ───────────────────────────────────────────────────
+// ── far queries: a box hierarchy over the sort order ─────────────────────────────────────────────────
 // A walk visits every point whose key lies within the bound of the query's key: a query that is metres from every
 // target point (a pair started from a wrong pre-alignment, a rotation far from the right one) walks most of the
 // cloud — ~1 400 candidates instead of ~10 — and a wave waits for its longest lane.  So a walk that has taken
-// SWEEP_FAR_ROUNDS rounds gives up (sweepf_nn_far, below) and the search is finished by a scan over BLOCKS of SWEEP_BLOCK consecutive sorted
-// positions, each with the bounding box of its float32 images (sbox[b] = min x, min y, max x, max y): a block whose box
-// is farther than the bound is skipped whole, the points of the others go through the same float32 filter and exact
-// test as in the walk.  In bearing order a block is a contiguous piece of wall (tight boxes: ~100 box tests and two or
-// three blocks of points per query); along a projection the boxes are loose and the scan degrades to the filter over
-// the points — never worse than the walk it replaces.  Exact: the box distance is computed with the very operations of
-// the point filter (monotone roundings), so it never exceeds the filter value of a point inside the box.
+// SWEEP_FAR_ROUNDS rounds gives up and the search is finished on a hierarchy of bounding boxes of the float32 images:
+// the leaves are BLOCKS of SWEEP_BLOCK consecutive sorted positions (in bearing order a contiguous piece of wall), every
+// inner node is the box of its two children — a complete binary tree in heap order over `leaves` (a power of two) blocks,
+// tree[1] the root, tree[leaves + b] the box of block b (min x, min y, max x, max y; an empty block is an empty box,
+// infinitely far from everything).  A query descends to the nearer child first, so the first block it looks at is (nearly)
+// the nearest and what it holds bounds the rest: ~20 box tests and two or three blocks of points per query, whatever its
+// distance.  (Flat versions, measured in round 3: testing all ~80 block boxes costs ~2 000 instructions per query, more
+// than everything else together; scanning the blocks that pass in index order offers a third of their points to the
+// exact test before the bound is tight.)
+// Exact: the box distance is computed with the very operations of the point filter (monotone roundings), so it never
+// exceeds the filter value of an image inside the box; the points go through the same float32 filter and exact test as
+// in the walk.
 constexpr int SWEEP_BLOCK = 16;
 #ifndef SWEEP_FAR_ROUNDS
 #define SWEEP_FAR_ROUNDS 24
 #endif
-
-// boxes of the blocks of m staged images (all threads of the workgroup; the images must be complete: barrier before)
-__device__ __forceinline__ void sweepf_build_boxes(const float4* sq, int m, float4* sbox, int tid, int nthreads) {
-    for (int b = tid; b * SWEEP_BLOCK < m; b += nthreads) {
-        const int i1 = min(m, (b + 1) * SWEEP_BLOCK);
-        float x0 = __builtin_inff(), y0 = __builtin_inff(), x1 = -__builtin_inff(), y1 = -__builtin_inff();
-        for (int i = b * SWEEP_BLOCK; i < i1; ++i) {
-            const float4 c = sq[i];
-            x0 = fminf(x0, c.x); y0 = fminf(y0, c.y); x1 = fmaxf(x1, c.x); y1 = fmaxf(y1, c.y);
-        }
-        sbox[b] = make_float4(x0, y0, x1, y1);
-    }
-}
-
 #ifdef ICPMI_DIAG
 static __device__ unsigned long long icpmi_dbg[16];      // diagnostic build: cycles of the phases of sweepf_top2_far (per lane-call, summed)
 #define DBG_T(v) const unsigned long long v = __builtin_readcyclecounter()
@@ -674,97 +665,101 @@ static __device__ unsigned long long icpmi_dbg[16];      // diagnostic build: cy
 #define DBG_T(v)
 #define DBG_ADD(k, a, b)
 #endif
-// One pass over the boxes of a far query.  Per box, with the very operations of the point filter (monotone roundings):
-//   lo = the filter value no image inside the box can undercut (nearest point of the box),
-//   hi = the filter value no image inside the box can exceed   (farthest corner).
-// A block that holds at least `need` points puts the query's need-th nearest point within its farthest corner, so the
-// smallest hi seen so far bounds the search before a single point has been looked at: as a filter threshold
-//   Tc = 1.001 hi_min + 1e5 e15^2
-// (>= the threshold SweepFQuery::bounds derives from the exact bound ((sqrt(hi_min) (1 + 1e-5) + 2 e15)^2: the images are
-// within e15 of the exact offsets; (a + b)^2 <= (1 + d) a^2 + (1 + 1/d) b^2 with d = 1e-4).  Blocks whose lo is within
-// the running threshold are noted in a bit mask — the loop over boxes is uniform across the wave; each lane then walks
-// its OWN bits (the lanes hold different queries: a loop that scanned every block somebody needs would run over all of
-// them — measured: two blocks per query and still the time of a full scan) and tests a block again before scanning it.
-// offer(i) is called for the points within the threshold and keeps T, the threshold of what the caller has found.
+
+// leaves of the tree over m points (a power of two, at least 2); the tree takes 2 * leaves entries of 16 B
+__host__ __device__ __forceinline__ int sweepf_tree_leaves(int m) {
+    int l = 2;
+    while (l * SWEEP_BLOCK < m) l <<= 1;
+    return l;
+}
+
+// build the tree of m staged images (all threads of the workgroup; the images must be complete: barrier before; holds a
+// barrier itself, the tree is complete after the caller's next one)
+__device__ __forceinline__ void sweepf_build_tree(const float4* sq, int m, float4* tree, int leaves, int tid, int nthreads) {
+    for (int b = tid; b < leaves; b += nthreads) {
+        const int i1 = min(m, (b + 1) * SWEEP_BLOCK);
+        float x0 = __builtin_inff(), y0 = __builtin_inff(), x1 = -__builtin_inff(), y1 = -__builtin_inff();
+        for (int i = b * SWEEP_BLOCK; i < i1; ++i) {
+            const float4 c = sq[i];
+            x0 = fminf(x0, c.x); y0 = fminf(y0, c.y); x1 = fmaxf(x1, c.x); y1 = fmaxf(y1, c.y);
+        }
+        tree[leaves + b] = make_float4(x0, y0, x1, y1);
+    }
+    __syncthreads();
+    for (int k = 1 + tid; k < leaves; k += nthreads) {                 // inner node k: the union of the leaves below it
+        int lo = k, hi = k;
+        while (lo < leaves) { lo = 2 * lo; hi = 2 * hi + 1; }
+        float x0 = __builtin_inff(), y0 = __builtin_inff(), x1 = -__builtin_inff(), y1 = -__builtin_inff();
+        for (int j = lo; j <= hi; ++j) {
+            const float4 c = tree[j];
+            x0 = fminf(x0, c.x); y0 = fminf(y0, c.y); x1 = fmaxf(x1, c.z); y1 = fmaxf(y1, c.w);
+        }
+        tree[k] = make_float4(x0, y0, x1, y1);
+    }
+}
+
+// float32 lower bound of the filter value (SweepFRound: fma(dx, dx, dy * dy)) of any image inside the box
+__device__ __forceinline__ float sweepf_box_s2(const float4 bb, float qx, float qy) {
+    const float dx = fmaxf(fmaxf(bb.x - qx, qx - bb.z), 0.0f), dy = fmaxf(fmaxf(bb.y - qy, qy - bb.w), 0.0f);
+    return __builtin_fmaf(dx, dx, dy * dy);
+}
+
+// The far scan of one query: depth-first over the tree, nearer child first, a subtree left out when its box is beyond
+// the filter threshold T.  No stack: `trail` holds one bit per level on the path from the root (is the sibling still to
+// be looked at?), the path itself is the node's index.  offer(i) is called for the points within T and lowers it.
 template <class Offer>
-__device__ __forceinline__ void sweepf_far_scan(const float4* sq, const float4* sbox, int m, const SweepFQuery& fq, int need,
+__device__ __forceinline__ void sweepf_far_scan(const float4* sq, const float4* tree, int leaves, int m, const SweepFQuery& fq,
                                                 const float& T, Offer offer) {
-    const int n_blocks = (m + SWEEP_BLOCK - 1) / SWEEP_BLOCK;
-    const int n_bound = (m - need + SWEEP_BLOCK) / SWEEP_BLOCK;        // blocks 0 .. n_bound-1 hold at least `need` points
-    const float kabs = 1e5f * fq.e15 * fq.e15;
-    float Tc = __builtin_inff();
-    // the points of block b against the filter, eight image loads in flight (the image copy is padded to whole blocks;
-    // entries past m are never offered)
-    const auto scan_block = [&](int b) {
-#pragma unroll
-        for (int e = 0; e < SWEEP_BLOCK / 8; ++e) {
-            const int i0 = b * SWEEP_BLOCK + e * 8;
-            float v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float2 c = *reinterpret_cast<const float2*>(sq + i0 + k);
-                const float ex = fq.x - c.x, ey = fq.y - c.y;
-                v[k] = __builtin_fmaf(ex, ex, ey * ey);
+    int node = 1;
+    unsigned trail = 0;
+    bool tested = true;                                                // the root is entered untested
+    for (;;) {
+        bool down = tested || !(sweepf_box_s2(tree[node], fq.x, fq.y) > T);          // NaN compares false: entered
+        if (down && node < leaves) {
+            const float la = sweepf_box_s2(tree[2 * node], fq.x, fq.y), lb = sweepf_box_s2(tree[2 * node + 1], fq.x, fq.y);
+            const bool b_first = lb < la;
+            const float l_near = b_first ? lb : la, l_far = b_first ? la : lb;
+            if (!(l_near > T)) {
+                trail = (trail << 1) | (l_far > T ? 0u : 1u);
+                node = 2 * node + (b_first ? 1 : 0);
+                tested = true;
+                continue;
             }
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (!(v[k] > fminf(T, Tc)) && i0 + k < m) offer(i0 + k);
+            down = false;                                              // both children are beyond the threshold
         }
-    };
-    for (int g0 = 0; g0 < n_blocks; g0 += 128) {                       // (one group up to 2 048 points)
-        unsigned long long mask[2] = {0, 0};
-        float lo_min = __builtin_inff();
-        int b_min = g0;
-        DBG_T(e0);
+        if (down) {
+            // a block: its points against the filter, eight image loads in flight (the image copy is padded to whole
+            // blocks; entries past m are never offered)
+            const int b = node - leaves;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int nb = min(64, n_blocks - g0 - 64 * h);
-#pragma unroll 8
-            for (int j = 0; j < nb; ++j) {                             // (unrolled: eight box loads in flight, not one LDS latency per box)
-                const int b = g0 + 64 * h + j;
-                const float4 bb = sbox[b];
-                const float ax = bb.x - fq.x, bx = fq.x - bb.z, ay = bb.y - fq.y, by = fq.y - bb.w;
-                const float lx = fmaxf(fmaxf(ax, bx), 0.0f), ly = fmaxf(fmaxf(ay, by), 0.0f);
-                const float hx = fmaxf(-ax, -bx), hy = fmaxf(-ay, -by);
-                const float lo = __builtin_fmaf(lx, lx, ly * ly);
-                const float hi = __builtin_fmaf(hx, hx, hy * hy);
-                if (b < n_bound) Tc = fminf(Tc, __builtin_fmaf(hi, 1.001f, kabs));      // NaN: fminf keeps Tc
-                mask[h] |= (unsigned long long)(lo > fminf(T, Tc) ? 0 : 1) << j;        // NaN compares false: scanned
-                b_min = lo < lo_min ? b : b_min;
-                lo_min = fminf(lo_min, lo);
+            for (int e = 0; e < SWEEP_BLOCK / 8; ++e) {
+                const int i0 = b * SWEEP_BLOCK + e * 8;
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float2 c = *reinterpret_cast<const float2*>(sq + i0 + k);
+                    const float ex = fq.x - c.x, ey = fq.y - c.y;
+                    v[k] = __builtin_fmaf(ex, ex, ey * ey);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (!(v[k] > T) && i0 + k < m) offer(i0 + k);
             }
         }
-        // the nearest box first (every lane at once): what it holds tightens the threshold for all the others
-        {
-            const unsigned long long bit = 1ull << ((b_min - g0) & 63);
-            const bool upper = b_min - g0 >= 64;
-            const bool set = ((upper ? mask[1] : mask[0]) & bit) != 0;
-            mask[0] &= upper ? ~0ull : ~bit;
-            mask[1] &= upper ? ~bit : ~0ull;
-            if (set) scan_block(b_min);
-        }
-        DBG_T(e1);
-        DBG_ADD(2, e0, e1);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            unsigned long long mk = mask[h];
-            while (mk) {
-                const int b = g0 + 64 * h + __builtin_ctzll(mk);
-                mk &= mk - 1;
-                const float4 bb = sbox[b];
-                const float lx = fmaxf(fmaxf(bb.x - fq.x, fq.x - bb.z), 0.0f), ly = fmaxf(fmaxf(bb.y - fq.y, fq.y - bb.w), 0.0f);
-                if (__builtin_fmaf(lx, lx, ly * ly) > fminf(T, Tc)) continue;
-                scan_block(b);
-            }
-        }
+        // back up to the nearest level whose sibling is still to be looked at
+        if (trail == 0) break;
+        const int up = __builtin_ctz(trail);
+        node = (node >> up) ^ 1;
+        trail = (trail >> up) ^ 1u;
+        tested = false;
     }
 }
 
 // finish a 1-NN search over all blocks (best / bpos: what the walk has found so far)
-__device__ __forceinline__ void sweepf_far_nn(const float4* sq, const double2* sxy, const float4* sbox, const SweepFQuery& fq, int m,
+__device__ __forceinline__ void sweepf_far_nn(const float4* sq, const double2* sxy, const float4* tree, int leaves, const SweepFQuery& fq, int m,
                                               double qx, double qy, double& best, int& bpos, float& T) {
     float W;
-    sweepf_far_scan(sq, sbox, m, fq, 1, T, [&](int i) {
+    sweepf_far_scan(sq, tree, leaves, m, fq, T, [&](int i) {
         const double s = sweep_d2(qx, qy, sxy[i]);
         if (s == best && i != bpos) {                                  // exact tie: the lowest original row wins
             if (sweepf_row(sq[i]) < sweepf_row(sq[bpos])) bpos = i;
@@ -777,7 +772,7 @@ __device__ __forceinline__ void sweepf_far_nn(const float4* sq, const double2* s
 // off the target): the same walk, abandoned after SWEEP_FAR_ROUNDS rounds for the scan over block boxes.  A separate
 // function on purpose — the same logic inside sweepf_nn / sweepf_top2 cost the fused ICP kernel 11 registers (spills at
 // six waves per SIMD) and a third of its speed on pairs that start close (measured, round 3).
-__device__ __forceinline__ int sweepf_nn_far(const float4* sq, const double2* sxy, const float4* sbox, const SweepF& f, int m, int dir,
+__device__ __forceinline__ int sweepf_nn_far(const float4* sq, const double2* sxy, const float4* tree, int leaves, const SweepF& f, int m, int dir,
                                              double uabs, double qx, double qy, double& d2_out) {
     const SweepFQuery fq(f, dir, uabs, qx, qy);
     double best = __builtin_inf();
@@ -810,7 +805,7 @@ __device__ __forceinline__ int sweepf_nn_far(const float4* sq, const double2* sx
         }
         if (far || !fq.polar || !w.wrap(m)) break;
     }
-    if (far) sweepf_far_nn(sq, sxy, sbox, fq, m, qx, qy, best, bpos, T);
+    if (far) sweepf_far_nn(sq, sxy, tree, leaves, fq, m, qx, qy, best, bpos, T);
     d2_out = best;
     return bpos;
 }
@@ -843,7 +838,7 @@ __device__ __forceinline__ void top2_offer(Top2& t, const float4* sq, double s, 
 #ifndef SWEEP_FAR_SEED_D2
 #define SWEEP_FAR_SEED_D2 0.25
 #endif
-__device__ __forceinline__ Top2 sweepf_top2_far(const float4* sq, const double2* sxy, const float4* sbox, const SweepF& f, int m, int dir,
+__device__ __forceinline__ Top2 sweepf_top2_far(const float4* sq, const double2* sxy, const float4* tree, int leaves, const SweepF& f, int m, int dir,
                                                 double uabs, double qx, double qy, int seed, double* diag = nullptr) {
     DBG_T(d0);
     const SweepFQuery fq(f, dir, uabs, qx, qy);
@@ -885,7 +880,7 @@ __device__ __forceinline__ Top2 sweepf_top2_far(const float4* sq, const double2*
 #ifdef ICPMI_DIAG
         if (diag) atomicAdd(diag, 4294967296.0);
 #endif
-        sweepf_far_scan(sq, sbox, m, fq, 3, T, [&](int i) {
+        sweepf_far_scan(sq, tree, leaves, m, fq, T, [&](int i) {
             if (i == t.p2 || (i == t.p1 && t.s1 < __builtin_inf())) return;
             top2_offer(t, sq, sweep_d2(qx, qy, sxy[i]), i, sweepf_row(sq[i]));
             fq.bounds(t.s3, W, T);
