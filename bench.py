@@ -95,14 +95,15 @@ def pmc_traffic(kernel_substr, workgroups):
     if doc.get("csrc_sha256") != csrc_signature():
         return None, (f"profiles/{os.path.basename(PMC_TRAFFIC)} was collected on csrc {doc.get('csrc_sha256')}, this build is "
                       f"{csrc_signature()}: stale, not quoted")
-    # A batch is up to four launches of the fused ICP code (csrc/icp2.hip: every pair up to 12 iterations on `workgroups`
+    # A batch is up to five launches of the fused ICP code (csrc/icp2.hip: every pair up to 12 iterations on `workgroups`
     # workgroups; the pairs still running, one per workgroup of an eighth as many, and whatever that leaves on 256 more; the
     # pairs with wide clouds, on a thirty-second): the bytes of the batch are their sum.  Below 1 024 pairs: one launch.
     B = workgroups
-    grids = {"icp2_fused_kernel": B}
+    grids = {"icp2_fused_kernel": B, "icp2_far_kernel": min(B, 256)}          # (the continuation of pairs that start far: none here, it looks and leaves)
     if B >= 1024:
         grids.update({"icp2_resume_kernel": max(256, B // 8), "icp2_resume_rest_kernel": 256, "icp2_wide_kernel": min(B, max(256, B // 32))})
-    key = [k for k in doc.get("kernels", {}) for name, grid in grids.items() if name + "<" in k and f"[{grid} workgroups]" in k]
+    key = [k for k in doc.get("kernels", {}) for name, grid in grids.items()
+           if (name + "<" in k or name + "(" in k) and f"[{grid} workgroups]" in k]
     if not key:
         return None, "kernel/grid not in the committed PMC summary"
     total = sum(doc["kernels"][k]["hbm_bytes_per_launch"] for k in key)
@@ -381,9 +382,10 @@ def bench_run_icp_pair(torch, dist, synth, rank, world, red_dev, steps, warmup, 
     ms_step = elapsed / steps * 1e3
     note = ("same candidate poses as config5_512: the like-for-like cost of adding the pre-alignment" if max_offset < 1.0 else
             "SURVEY 8d poses; the rotation search (the reference's algorithm, its result reproduced bit for bit) leaves "
-            "`registered_fraction` of these candidates within ICP's reach — the others start metres off, never settle, and "
-            "every row of such a pair walks a large part of its target each iteration (the reference's k-d tree does not care; "
-            "the sorted-sweep search does): they set this leg's time")
+            "`registered_fraction` of these candidates within ICP's reach — the others start metres off and never settle.  The "
+            "first launch hands such a pair (mean squared error of its first step above 1 m^2) to "
+            "icp2_far_kernel, whose searches give up a long walk for a box hierarchy over the sort order (same matches, same "
+            "bits); one pair that circles for 150 iterations with a quarter of its rows searching sets this leg's time")
     return {"workload": "BASELINE config 5 as slam.py:575-579 runs it: 512 candidates of one current scan (target pose within "
                         f"{max_offset} m / {max_yaw_deg} deg: d ~ U(0, {max_offset}), direction uniform, yaw ~ U(-{max_yaw_deg}, {max_yaw_deg})), "
                         "each _run_icp_pair = rotation_search (voxel 0.15, 240 coarse + ~31 fine angles) "
@@ -696,7 +698,9 @@ def bench_raycast(torch, synth, n_scans, with_cpu):
                           "cell_updates": one_cells, "cells_per_sec": round(one_cells / one_s, 1),
                           "roofline": {"bound": "hbm", "achieved": round(one_bytes / one_s / 1e9, 3), "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "frac": round(one_bytes / one_s / 1e9 / HBM_PEAK_GBS, 6),
-                                       "note": "two dependent launches (count, finalise): launch-latency bound, ~2 MB of traffic"}}
+                                       "note": "ONE launch (ray_owner_kernel: a workgroup per 64 x 64 tile of the scan's box takes the beams that cross it, "
+                                               "counts in LDS and applies hit / miss replay and clip to its own cells; no counter region): "
+                                               "bound by the origin tiles' workgroups (every beam crosses them), ~14 us of kernel"}}
     # ... and the call slam.py:557 makes: NumPy origin and hits in, through OccupancyGrid2D.update_scan (upload included)
     g.reset()
     host_s = timed(torch, lambda: g.update_scan(org[0], hits[0]))

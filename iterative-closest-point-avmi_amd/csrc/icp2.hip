@@ -75,10 +75,10 @@ struct Icp2Args {
     int32_t* wide_list;       // pairs the first launch leaves to the wider shape (when the caller gave a workspace): the second
     int32_t* wide_count;      // launch walks this list instead of starting a workgroup per pair of the batch just to look
     // Pairs that start FAR from their target (a candidate whose pre-alignment is wrong: every row metres from the nearest
-    // wall) walk most of the sorted target in every search.  A first launch that finds the mean squared nearest-neighbour
-    // distance of iteration 0 above far_d2 parks the pair after that iteration (same state as above) on far_list, and
-    // icp2_far_kernel continues it with searches that give up long walks for a scan over block boxes (sweep.hpp).  Same
-    // matches, same arithmetic: the pair's result does not depend on which kernel finished it.
+    // wall) walk most of the sorted target in every search.  A first launch that finds the mean squared error of step 0
+    // (the convergence test of iteration 1 has it anyway) above far_d2 parks the pair after iteration 1 (same state as
+    // above) on far_list, and icp2_far_kernel continues it with searches that give up long walks for a box hierarchy
+    // (sweep.hpp).  Same matches, same arithmetic: the pair's result does not depend on which kernel finished it.
     int32_t* far_list;        // nullptr: never
     int32_t* far_count;
     double far_d2;            // +inf: never
@@ -177,12 +177,16 @@ __device__ __forceinline__ float wave_uniform(float v) {
 
 // Finish step it-1 (icp.py:215-220: mean squared error of the step, its change, convergence) and test the inlier
 // count of step it (icp.py:186).  Every lane of the lead wave evaluates the same values; the writer lane stores.
-__device__ __forceinline__ bool finish_step(double* ctrl, int it, double err_sum, double inliers, int N, bool has_corr,
-                                            int need, double error_threshold, bool writer) {
-    bool stop = false;
+// Returns FIN_STOP when the pair is done, FIN_FAR when step 0 left a mean squared error above far_err (the pair goes to the
+// far continuation after this iteration, launch_icp2), else FIN_GO.
+constexpr int FIN_GO = 0, FIN_STOP = 1, FIN_FAR = 2;
+__device__ __forceinline__ int finish_step(double* ctrl, int it, double err_sum, double inliers, int N, bool has_corr,
+                                           int need, double error_threshold, bool writer, double far_err) {
+    bool stop = false, far = false;
     if (it > 0) {
         const double err = err_sum / (double)N, delta = fabs(ctrl[CTRL_PREV] - err);
         stop = delta < error_threshold;
+        far = it == 1 && err > far_err;
         if (writer) {
             ctrl[CTRL_ERR] = err; ctrl[CTRL_DELTA] = delta; ctrl[CTRL_PREV] = err; ctrl[CTRL_ITERS] = (double)it;
             if (stop) ctrl[CTRL_STATUS] = (double)ICPMI_ST_CONVERGED;
@@ -192,7 +196,7 @@ __device__ __forceinline__ bool finish_step(double* ctrl, int it, double err_sum
         stop = true;
         if (writer) { ctrl[CTRL_STATUS] = (double)ICPMI_ST_FEW_INLIERS; ctrl[CTRL_ITERS] = (double)it; }
     }
-    return stop;
+    return stop ? FIN_STOP : (far ? FIN_FAR : FIN_GO);
 }
 
 // R_total = R R_total, t_total = t_total R^T + t: icp.py:210-211
@@ -371,11 +375,10 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
             }
         }
         bool stopped = false;
-        // iteration 0 of a first launch: is this pair one for the far continuation?  (sum = the squared nearest-neighbour
-        // distances of all rows; the continuation runs iterations 1 .. max_iterations - 1)
-        const auto far_start = [&](int it, double sum) {
-            return !RESUME && it == 0 && sum > a.far_d2 * (double)N && N <= ICP2_FAR_THREADS * ICP2_FAR_SMAX && M <= ICP2_FAR_POINTS;
-        };
+        // a first launch hands a pair whose FIRST step leaves a mean squared error above far_d2 to the far continuation, which
+        // runs iterations 2 .. max_iterations - 1 (the test rides on the convergence test of iteration 1: no arithmetic of its own)
+        const double far_err = !RESUME && a.max_iterations > 2 && N <= ICP2_FAR_THREADS * ICP2_FAR_SMAX && M <= ICP2_FAR_POINTS
+                                   ? a.far_d2 : __builtin_inf();
 #ifdef ICPMI_DIAG
         double dg_nn = 0, dg_red = 0, dg_lead = 0, dg_apply = 0;
 #endif
@@ -504,7 +507,6 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                     if (!in[s]) continue;
                     const double2 q = sxy[pos[s]], nm = snrm[pos[s]];
                     const double dx = px[s] - q.x, dy = py[s] - q.y;
-                    if (!RESUME && it == 0) acc[10] += dx * dx + dy * dy;   // (finish_step ignores the error slot at iteration 0: it carries this sum to the far test)
                     if (has_corr) {                                   // the search's squared distance, recomputed bit for bit
                         double s2 = 0.0;
                         s2 += dx * dx;
@@ -519,14 +521,14 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                     acc[6] += c * bi;      acc[7] += nm.x * bi;   acc[8] += nm.y * bi;
                     acc[9] += 1.0;
                 }
-                acc[10] += e_part;
+                acc[10] = e_part;
                 wave_totals<11>(redA, acc);
                 __syncthreads();
                 DIAG_SET(c2);
                 if (lead) {
                     combine_totals<11>(redA, NWAVES, acc);
-                    const bool stop = finish_step(ctrl, it, acc[10], acc[9], N, has_corr, need, a.error_threshold, tid == 0);
-                    if (tid == 0) ctrl[CTRL_STOP] = stop ? 1.0 : (far_start(it, acc[10]) ? 2.0 : 0.0);     // (before the solve: acc[10] dies here)
+                    const int fin = finish_step(ctrl, it, acc[10], acc[9], N, has_corr, need, a.error_threshold, tid == 0, far_err);
+                    const bool stop = fin == FIN_STOP;
                     if (!stop) {
                         double A[3][3] = {{acc[0], acc[1], acc[2]}, {acc[1], acc[3], acc[4]}, {acc[2], acc[4], acc[5]}};
                         double rhs[3] = {acc[6], acc[7], acc[8]}, x[3];
@@ -545,6 +547,7 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                             ctrl[CTRL_T] = t[0]; ctrl[CTRL_T + 1] = t[1];
                         }
                     }
+                    if (tid == 0) ctrl[CTRL_STOP] = (double)fin;
                 }
                 __syncthreads();
             } else {
@@ -554,7 +557,6 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 for (int s = 0; s < ICP2_SMAX; ++s) {
                     if (!in[s]) continue;
                     const double2 q = sxy[pos[s]];
-                    if (!RESUME && it == 0) { const double dx = px[s] - q.x, dy = py[s] - q.y; m[5] += dx * dx + dy * dy; }
                     if (has_corr) {                                   // the search's squared distance, recomputed bit for bit
                         const double dx = px[s] - q.x, dy = py[s] - q.y;
                         double s2 = 0.0;
@@ -566,21 +568,21 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                     }
                     m[0] += px[s]; m[1] += py[s]; m[2] += q.x; m[3] += q.y; m[4] += 1.0;
                 }
-                m[5] += e_part;
+                m[5] = e_part;
                 wave_totals<6>(redA, m);
                 __syncthreads();
                 DIAG_SET(c2);
                 if (lead) {
                     combine_totals<6>(redA, NWAVES, m);
-                    const bool stop = finish_step(ctrl, it, m[5], m[4], N, has_corr, need, a.error_threshold, tid == 0);
+                    const int fin = finish_step(ctrl, it, m[5], m[4], N, has_corr, need, a.error_threshold, tid == 0, far_err);
                     if (tid == 0) {
-                        ctrl[CTRL_STOP] = stop ? 1.0 : (far_start(it, m[5]) ? 2.0 : 0.0);
+                        ctrl[CTRL_STOP] = (double)fin;
                         ctrl[CTRL_MP] = m[0] / m[4]; ctrl[CTRL_MP + 1] = m[1] / m[4];
                         ctrl[CTRL_MQ] = m[2] / m[4]; ctrl[CTRL_MQ + 1] = m[3] / m[4];
                     }
                 }
                 __syncthreads();
-                if (ctrl[CTRL_STOP] == 1.0) { stopped = true; break; }
+                if (ctrl[CTRL_STOP] == (double)FIN_STOP) { stopped = true; break; }
                 const double mpx = ctrl[CTRL_MP], mpy = ctrl[CTRL_MP + 1], mqx = ctrl[CTRL_MQ], mqy = ctrl[CTRL_MQ + 1];
                 // centred cross-covariance, icp.py:199-201
                 double W[4] = {0, 0, 0, 0};
@@ -610,7 +612,7 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 __syncthreads();
             }
             DIAG_T(c3);
-            if (ctrl[CTRL_STOP] == 1.0) { stopped = true; break; }
+            if (ctrl[CTRL_STOP] == (double)FIN_STOP) { stopped = true; break; }
             // ── apply to ALL rows; squared residual against this search's matches, icp.py:212-215 ─
             const double r0 = ctrl[CTRL_R], r1 = ctrl[CTRL_R + 1], r2 = ctrl[CTRL_R + 2], r3 = ctrl[CTRL_R + 3];
             const double t0 = ctrl[CTRL_T], t1 = ctrl[CTRL_T + 1];
@@ -629,14 +631,14 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 se += ey * ey;
                 e_part += se;
             }
-            if (!RESUME && it == 0 && ctrl[CTRL_STOP] == 2.0) break;
+            if (!RESUME && it == 1 && ctrl[CTRL_STOP] == (double)FIN_FAR) break;
             DIAG_T(c4);
 #ifdef ICPMI_DIAG
             DIAG_ADD(dg_nn, c0, c1); DIAG_ADD(dg_red, c1, c2); DIAG_ADD(dg_lead, c2, c3); DIAG_ADD(dg_apply, c3, c4);
             if (tid == 0) { res[4] = dg_nn; res[5] = dg_red; res[6] = dg_lead; res[7] = dg_apply; }
 #endif
         }
-        const bool far_parked = !RESUME && !stopped && ctrl[CTRL_STOP] == 2.0;      // left after iteration 0
+        const bool far_parked = !RESUME && !stopped && ctrl[CTRL_STOP] == (double)FIN_FAR;      // left after iteration 1
         if (!RESUME && !stopped && (far_parked || it_end < a.max_iterations)) {
             // parked for the second stage: rows and matches as they are, totals through the result record
 #pragma unroll
@@ -829,11 +831,12 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     const int stage2_grid = n_pairs / 8 > 256 ? n_pairs / 8 : 256;
     // the launch for wide clouds: a thirty-second (a launch of 4 096 workgroups that find an empty list still takes 100 us)
     const int wide_grid = n_pairs < 256 ? n_pairs : (n_pairs / 32 > 256 ? n_pairs / 32 : 256);
-    // option ICP2_FAR = the mean squared distance (m^2) of iteration 0 above which a pair goes to the far continuation
-    // (default 0.5: 0.7 m rms — the candidates ICP converges from by itself stay below it; 0 = never)
-    double far_d2 = 0.5;
+    // option ICP2_FAR = the mean squared error (m^2) of the first step above which a pair goes to the far continuation
+    // (default 1: one metre rms — the candidates ICP converges from by itself stay below it: with 0.5 some of them are
+    // sent over and the 16 384-pair batch takes 5.7 instead of 5.05 ms; 0 = never)
+    double far_d2 = 1.0;
     if (const char* e = option("ICP2_FAR")) far_d2 = atof(e);
-    const bool far_ok = have_ws && in_lds && want_filter && far_d2 > 0.0 && p->max_iterations > 1;
+    const bool far_ok = have_ws && in_lds && want_filter && far_d2 > 0.0 && p->max_iterations > 2;
     if (have_ws && (two_stage || T2 || far_ok)) {
         unsigned char* w = (unsigned char*)workspace;
         a.st_xy = (double2*)w;
@@ -880,7 +883,7 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
 #undef ICPMI_ICP2_GO2
     if (a.far_list) {                                       // after every first launch (the wide one has joined the stream)
         Icp2Args c = a;
-        c.resume = 1; c.it_begin = 1; c.it_limit = 0x7fffffff; c.skip_over = 0; c.n_lo = -1; c.m_lo = 0;
+        c.resume = 1; c.it_begin = 2; c.it_limit = 0x7fffffff; c.skip_over = 0; c.n_lo = -1; c.m_lo = 0;
         int cap = 64;
         while (cap < max_tgt_n && cap < ICP2_FAR_POINTS) cap <<= 1;
         c.lds_points = cap;

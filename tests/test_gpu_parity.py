@@ -1412,7 +1412,7 @@ def test_submap_translation_refinement_on_the_device_and_on_the_host(uicp):
 
 @pytest.mark.parametrize("method", ["point_to_line", "point_to_point"])
 def test_far_pairs_finish_on_the_far_continuation_with_the_same_bits(uicp, libopt, method):
-    """Pairs that start metres from their target leave the first launch after iteration 0 and are finished by
+    """Pairs that start metres from their target leave the first launch after iteration 1 and are finished by
     icp2_far_kernel (walks given up for the scan over block boxes).  Same matches, same arithmetic: every result equals the
     one of the plain path (option ICP2_FAR = 0), whether the threshold sends the far pairs only (default) or every pair."""
     from icpmi import batch, synth

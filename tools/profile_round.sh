@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write --output-format csv -- p
 python3 $R/tools/profile_summary.py pmc $(ls $OUT/fetch/*/*counter_collection.csv | head -1) $(ls $OUT/write/*/*counter_collection.csv | head -1) > $OUT/${TAG}_pmc_traffic.json
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $OUT/mixa --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/mixa.json 2> $OUT/mixa.err
 rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_WAVES SQ_WAIT_ANY SQ_WAVE_CYCLES -d $OUT/mixb --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/mixb.json 2> $OUT/mixb.err
-python3 $R/tools/pmc_instruction_mix.py $(ls $OUT/mixa/*/*counter_collection.csv | head -1) $(ls $OUT/mixb/*/*counter_collection.csv | head -1) icp2_fused icp2_resume icp2_wide prep_targets voxel_small nn_batch rotation_scores rotation_search_batch ray_ > $OUT/${TAG}_pmc_instruction_mix.json
+python3 $R/tools/pmc_instruction_mix.py $(ls $OUT/mixa/*/*counter_collection.csv | head -1) $(ls $OUT/mixb/*/*counter_collection.csv | head -1) icp2_fused icp2_resume icp2_wide icp2_far prep_targets voxel_small nn_batch rotation_scores rotation_search_batch ray_ > $OUT/${TAG}_pmc_instruction_mix.json
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mixa $OUT/mixb
 # the bench line reads the traffic summary from profiles/ (and refuses one measured on other kernel sources)
 cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json
