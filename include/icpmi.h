@@ -83,7 +83,9 @@ const char* icpmi_strerror(int code);
  * unsets).  Names (with or without the ICPMI_ prefix): ICP2_SIDE (0: no side
  * streams), ICP2_SHAPE ("TxS": workgroup shape of the fused ICP), ICP2_FILTER
  * (0: no float32 filter), ICP2_STAGES (1: one launch, 2: two stages also for
- * point_to_point), POLAR (0 never / 2 always the bearing order), PREP_KNN
+ * point_to_point), ICP2_FAR (mean squared error in m^2 of a pair's first step
+ * above which it finishes on the kernel for far queries; default 1, 0: never),
+ * POLAR (0 never / 2 always the bearing order), PREP_KNN
  * (grid | sweep), RAYCAST (atomic | tiles | owner: the pass of the occupancy
  * update), RT_WGS (resident workgroups of the tile pass), RS_BATCH (full: the
  * batched rotation search scores every angle; projection: no bearing order).
@@ -152,8 +154,11 @@ int icpmi_p2l_solve_2d(const double* src, int32_t n_src, const double* tgt, cons
  * state in registers; `normals` is then not read, and `workspace` is optional:
  * given, a point_to_line batch of >= 1024 pairs runs in two stages — every pair
  * up to 12 iterations, then the pairs still running, parked there with their
- * moving rows and matches, together in a second launch — which gives the same
- * results bit for bit, sooner).  Without `prepared`, or for 3-D / larger
+ * moving rows and matches, together in a second launch — and a pair of any
+ * batch whose first step leaves a mean squared error above option ICP2_FAR (it
+ * starts metres from its target) is parked likewise and finished by the kernel
+ * for far queries; both give the same results bit for bit, sooner).  Without
+ * `prepared`, or for 3-D / larger
  * sources, the exhaustive LDS-tiled kernel runs and needs `workspace` (and
  * `normals` for point_to_line).  Results agree. */
 size_t icpmi_icp_workspace_bytes(int32_t n_pairs, int32_t max_src_n, int32_t dim);
