@@ -1433,6 +1433,28 @@ def test_far_pairs_finish_on_the_far_continuation_with_the_same_bits(uicp, libop
             assert rot_err(out[None][0][i], out[None][1][i], Ro, to) < FRO_TOL, i
 
 
+def test_far_continuation_with_rejection_and_mixed_sizes(uicp, libopt):
+    """The far continuation under max_corr_dist (rows drop out of the solve, a pair may stop on too few inliers) and in a
+    batch that mixes clouds it can hold (<= 2 048 rows) with ones it cannot (a 4 096-beam scan: left to the launch that
+    started it): every result equals the plain path's."""
+    from icpmi import batch, synth
+    B = 24
+    srcs, tgts = synth.loop_closure_batch(B, seed0=4700, shared_source=False, max_offset=2.5, max_yaw_deg=15.0)
+    base = (0.5, -0.3, 0.1)
+    for i in (3, 11):                                                   # two pairs of 4 096 beams: ~2 800 rows after the filter
+        srcs[i] = synth.scan(base, 99000 + i, n_beams=4096)
+        tgts[i] = synth.scan((base[0] + 1.5, base[1] - 1.0, base[2] + 0.2), 99100 + i, n_beams=4096)
+    for mcd in (None, 0.8):
+        out = {}
+        for far in ("0", "1e-12", None):
+            libopt.setenv("ICP2_FAR", far) if far else libopt.delenv("ICP2_FAR")
+            R, t, err, info = batch.icp_batch(srcs, tgts, 1e-10, 50, 0.04, None, None, "point_to_line", 12, max_corr_dist=mcd)
+            out[far] = (R, t, err, info["iters"], info["status"])
+        for far in ("1e-12", None):
+            for a, b in zip(out["0"], out[far]):
+                assert np.array_equal(a, b, equal_nan=True), (mcd, far)
+
+
 def test_far_continuation_beside_the_two_stages(uicp, libopt):
     """A batch large enough for the two-stage run (>= 1 024 pairs) with far pairs in it: first stage, second stage and far
     continuation together give the bits of the single plain launch."""
