@@ -208,6 +208,13 @@ __device__ __forceinline__ void accumulate_step(double* ctrl, const double (&r)[
     ctrl[CTRL_TT] = (tt0 * r[0] + tt1 * r[1]) + t[0]; ctrl[CTRL_TT + 1] = (tt0 * r[2] + tt1 * r[3]) + t[1];
 }
 
+// far continuation: a searching row's query on its way to the lane that runs the search, and the answer on its way back
+union FarSlot {
+    struct { double x, y; int seed, pad; } in;
+    struct { double s1, s3; int p1, p2; } out;
+};
+static_assert(sizeof(FarSlot) == 24, "24 B per row");
+
 template <int THREADS, int ICP2_SMAX, bool TGT_LDS, bool FILT, bool RESUME, bool FAR = false>
 __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
@@ -246,6 +253,8 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
     static_assert(!FAR || (FILT && RESUME), "the far continuation: filter images, parked state");
     float4* lds_tree = reinterpret_cast<float4*>(dyn + (size_t)a.lds_points * 48 + 32);    // FAR: box hierarchy over blocks of 16 images (sweep.hpp)
     const int tree_leaves = sweepf_tree_leaves(M);
+    // FAR: ICP2_SMAX slots per lane, each wave its own stretch (behind the largest tree: 2 * lds_points bytes)
+    FarSlot* far_q = reinterpret_cast<FarSlot*>(dyn + (size_t)a.lds_points * 50 + 32) + (size_t)(threadIdx.x / ICPMI_WAVE) * (ICPMI_WAVE * ICP2_SMAX);
     __shared__ int rt_bits;                                      // max(|x - ox|, |y - oy|) over the target, float32 bits
     if (FILT && tid == 0) rt_bits = 0;
 
@@ -455,21 +464,51 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                     }
             } else {
                 const bool centred = !RESUME && it < ICP2_CENTRED_ITERS;
+                // The far continuation packs the searching rows of a wave: a far search costs thousands of instructions and
+                // a wave pays for one per row slot in which ANY lane searches — with a quarter of the rows searching, both
+                // slots, at a quarter of the lanes.  The queries of all slots go through the wave's stretch of LDS to the
+                // low lanes (a slot's rows stay neighbours there) and the answers come back the same way: one round of
+                // searches per 64 searching rows.  Wave-private: no barrier, LDS operations of a wave complete in order.
+                int slot[ICP2_SMAX];
+                if constexpr (FAR) {
+                    int nq = 0;
+#pragma unroll
+                    for (int s = 0; s < ICP2_SMAX; ++s) {
+                        const unsigned long long bal = __ballot(srch[s]);
+                        slot[s] = nq + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                        nq += __popcll(bal);
+                        if (srch[s]) {
+                            FarSlot e;
+                            e.in.x = px[s]; e.in.y = py[s]; e.in.seed = pos[s]; e.in.pad = 0;
+                            far_q[slot[s]] = e;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int j = tid & (ICPMI_WAVE - 1); j < nq; j += ICPMI_WAVE) {
+                        const FarSlot e = far_q[j];
+#ifdef ICPMI_DIAG
+                        const Top2 r = sweepf_top2_far(lds_sq, sxy, lds_tree, tree_leaves, filt, M, dir, uabs, e.in.x, e.in.y, e.in.seed, &res[11]);
+#else
+                        const Top2 r = sweepf_top2_far(lds_sq, sxy, lds_tree, tree_leaves, filt, M, dir, uabs, e.in.x, e.in.y, e.in.seed);
+#endif
+                        FarSlot o;
+                        o.out.s1 = r.s1; o.out.s3 = r.s3; o.out.p1 = r.p1; o.out.p2 = r.p2;
+                        far_q[j] = o;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
                 for (int s = 0; s < ICP2_SMAX; ++s)
                     if (srch[s]) {
                         Top2 t2;
-                        // (Tried: the searching rows of the far continuation queued in LDS and worked off by the lanes in order — a
-                        // quarter of the rows searching is then a quarter of the waves, once, instead of every wave twice.  Slower,
-                        // 7.8 against 6.4 ms on the 3 m / 20 degree candidates: the lanes of a wave then hold rows from all over the
-                        // scan, their block masks differ more, and a wave's far scan is bound by its own dependent chain, not by
-                        // the issue slots it shares.)
+                        // (Tried first: ONE queue for the whole workgroup, worked off by its lanes in order — 7.8 against 6.4 ms
+                        // on the 3 m / 20 degree candidates: the lanes of a wave then hold rows from all over the scan and
+                        // their descents diverge; two barriers more per iteration.)
                         if constexpr (FAR) {
-#ifdef ICPMI_DIAG
-                            t2 = sweepf_top2_far(lds_sq, sxy, lds_tree, tree_leaves, filt, M, dir, uabs, px[s], py[s], pos[s], &res[11]);
-#else
-                            t2 = sweepf_top2_far(lds_sq, sxy, lds_tree, tree_leaves, filt, M, dir, uabs, px[s], py[s], pos[s]);
-#endif
+                            const FarSlot o = far_q[slot[s]];
+                            t2.p1 = o.out.p1; t2.p2 = o.out.p2; t2.s1 = o.out.s1; t2.s2 = o.out.s1; t2.s3 = o.out.s3;
                         }
                         else if constexpr (FILT) t2 = sweepf_top2(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], centred);
                         else t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], centred);
@@ -887,7 +926,8 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
         int cap = 64;
         while (cap < max_tgt_n && cap < ICP2_FAR_POINTS) cap <<= 1;
         c.lds_points = cap;
-        const size_t lds = (size_t)cap * 48 + 32 + 32 * (size_t)sweepf_tree_leaves(cap);    // the filter layout + the box hierarchy
+        // the filter layout + the box hierarchy (2 B per point at most) + a slot per row a workgroup can hold
+        const size_t lds = (size_t)cap * 50 + 32 + sizeof(FarSlot) * (size_t)(ICP2_FAR_THREADS * ICP2_FAR_SMAX);
         if (hipFuncSetAttribute((const void*)icp2_far_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return ICPMI_ERR_HIP;
         icp2_far_kernel<<<n_pairs < 256 ? n_pairs : 256, ICP2_FAR_THREADS, lds, st>>>(c);
