@@ -109,6 +109,11 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise IcpmiError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                              "(or `make -C iterative-closest-point-avmi_amd/csrc`). There is no CPU fallback.")
+        # torch first: it ships its own HIP runtime (libamdhip64 inside the wheel), and the process must hold ONE — the
+        # streams and allocations torch hands us have to belong to the runtime our launches go through.  Loaded before
+        # torch, libicpmi.so would bring in /opt/rocm's copy and torch its own beside it: every launch then fails with
+        # a HIP runtime error (seen: build() followed by smoke() in one process).
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             f = getattr(L, name)          # AttributeError here means the .so is stale
