@@ -360,12 +360,21 @@ struct RsbArgs {
 
 typedef float rsb_v2f __attribute__((ext_vector_type(2)));
 
+// rounds of a row's walk before the box hierarchy takes over (sweep.hpp: sweepf_nn_far): most coarse angles the bounds
+// cannot exclude put the rows decimetres to metres off, the fine grid lies about the winner
+#ifndef RSB_COARSE_ROUNDS
+#define RSB_COARSE_ROUNDS 6
+#endif
+#ifndef RSB_FINE_ROUNDS
+#define RSB_FINE_ROUNDS SWEEP_FAR_ROUNDS
+#endif
+
 // one angle, exactly: mean over the rows of (distance to the nearest target point)^2, features.py:213-218.
 // A wave per angle; `limit` (a score already reached by another angle) lets it give up as soon as the part summed so
 // far exceeds it (then +inf returns: it cannot be the minimum).
 __device__ __forceinline__ double rsb_score_angle(const double2* src_c, int n, const float4* sq, const double2* sxy, const SweepF& filt,
                                                   int m, int dir, double uabs, double c, double s, double shx, double shy,
-                                                  const volatile double* limit, bool prune, const float4* tree, int leaves) {
+                                                  const volatile double* limit, bool prune, const float4* tree, int leaves, int walk_rounds) {
     double acc = 0.0;
     const int lane = lane_id();
     for (int first = 0; first < n; first += ICPMI_WAVE) {             // wave-uniform trip count
@@ -374,7 +383,7 @@ __device__ __forceinline__ double rsb_score_angle(const double2* src_c, int n, c
             const double2 p = src_c[i];
             const double qx = (p.x * c + p.y * -s) + shx, qy = (p.x * s + p.y * c) + shy;   // src_c @ R.T + mu_t, features.py:216
             double d2;
-            (void)sweepf_nn_far(sq, sxy, tree, leaves, filt, m, dir, uabs, qx, qy, d2);
+            (void)sweepf_nn_far(sq, sxy, tree, leaves, filt, m, dir, uabs, qx, qy, d2, walk_rounds);
             const double d = sqrt(d2);                                  // KDTree distance ...
             acc += d * d;                                               // ... squared, features.py:218
         }
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
         const int k = order[item];
         if ((double)lb[k] > *(volatile double*)&best_score) break;              // bounds ascend: nothing further on can win
         const double sc_k = rsb_score_angle(src_c, n, sq, sxy, filt, m, dir, uabs, a.coarse_cs[2 * k], a.coarse_cs[2 * k + 1], mutx, muty,
-                                            &best_score, prune, tree, leaves);
+                                            &best_score, prune, tree, leaves, RSB_COARSE_ROUNDS);
         if (lane_id() == 0) {
             scores[k] = sc_k;
             atomicAdd(&n_evals, 1);
@@ -581,7 +590,7 @@ __global__ __launch_bounds__(RSB_THREADS, 4) void rotation_search_batch_kernel(R
     __syncthreads();
     const double* fcs = a.fine_cs + (size_t)kbest * a.max_fine * 2;
     for (int j = wave_id(); j < nf; j += RSB_WAVES) {
-        const double sc_j = rsb_score_angle(src_c, n, sq, sxy, filt, m, dir, uabs, fcs[2 * j], fcs[2 * j + 1], mutx, muty, &best_score, prune, tree, leaves);
+        const double sc_j = rsb_score_angle(src_c, n, sq, sxy, filt, m, dir, uabs, fcs[2 * j], fcs[2 * j + 1], mutx, muty, &best_score, prune, tree, leaves, RSB_FINE_ROUNDS);
         if (lane_id() == 0) {
             scores[j] = sc_j;
             atomicAdd(&n_evals, 1);

@@ -772,8 +772,10 @@ __device__ __forceinline__ void sweepf_far_nn(const float4* sq, const double2* s
 // off the target): the same walk, abandoned after SWEEP_FAR_ROUNDS rounds for the scan over block boxes.  A separate
 // function on purpose — the same logic inside sweepf_nn / sweepf_top2 cost the fused ICP kernel 11 registers (spills at
 // six waves per SIMD) and a third of its speed on pairs that start close (measured, round 3).
+// max_rounds: rounds of the walk before the tree takes over.  The first few are never wasted — what they meet bounds the
+// descent (started without any bound it costs twice as much) —, more pay only where most queries end within them.
 __device__ __forceinline__ int sweepf_nn_far(const float4* sq, const double2* sxy, const float4* tree, int leaves, const SweepF& f, int m, int dir,
-                                             double uabs, double qx, double qy, double& d2_out) {
+                                             double uabs, double qx, double qy, double& d2_out, int max_rounds = SWEEP_FAR_ROUNDS) {
     const SweepFQuery fq(f, dir, uabs, qx, qy);
     double best = __builtin_inf();
     float W = __builtin_inff(), T = __builtin_inff();
@@ -785,7 +787,7 @@ __device__ __forceinline__ int sweepf_nn_far(const float4* sq, const double2* sx
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         while (w.more()) {
-            if (++rounds > SWEEP_FAR_ROUNDS) { far = true; break; }
+            if (++rounds > max_rounds) { far = true; break; }
             const SweepFRound r(sq, w, fq, W, T);
             if (r.pr || r.pl) {                                        // might win (or tie): the exact test
 #pragma unroll
@@ -832,11 +834,11 @@ __device__ __forceinline__ void top2_offer(Top2& t, const float4* sq, double s, 
     }
 }
 
+// (measured on the 3 m / 20 degree candidates, ICP half: 24 rounds 6.35 ms, 12 5.73, 6 5.46, 3 5.42 — and 3.84 once rows far
+// from their previous match stopped skipping the walk altogether: two or three rounds about the seed are what gives the
+// descent its bound; 1 / 2 / 3 / 4 rounds 3.84 / 3.86 / 3.84 / 3.95)
 #ifndef SWEEP_FAR_ROUNDS_TOP2
-#define SWEEP_FAR_ROUNDS_TOP2 12
-#endif
-#ifndef SWEEP_FAR_SEED_D2
-#define SWEEP_FAR_SEED_D2 0.25
+#define SWEEP_FAR_ROUNDS_TOP2 3
 #endif
 __device__ __forceinline__ Top2 sweepf_top2_far(const float4* sq, const double2* sxy, const float4* tree, int leaves, const SweepF& f, int m, int dir,
                                                 double uabs, double qx, double qy, int seed, double* diag = nullptr) {
@@ -853,11 +855,10 @@ __device__ __forceinline__ Top2 sweepf_top2_far(const float4* sq, const double2*
     SweepFWalk w(from_seed ? seed - 1 : h0 - 1, h0, m, fq.u);
     const int skip = seeded ? seed : -1;                               // the seed is in the list already
     int rounds = 0;
-    // a row half a metre from its previous match is far from everything, as a rule: straight to the scan
-    bool far = seeded && t.s1 > SWEEP_FAR_SEED_D2;
+    bool far = false;
     DBG_T(d1);
 #pragma unroll 1
-    for (int pass = 0; pass < 2 && !far; ++pass) {
+    for (int pass = 0; pass < 2; ++pass) {
         while (w.more()) {
             if (++rounds > SWEEP_FAR_ROUNDS_TOP2) { far = true; break; }
             const SweepFRound r(sq, w, fq, W, T);
