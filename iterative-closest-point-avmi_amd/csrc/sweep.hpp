@@ -640,8 +640,9 @@ __device__ __forceinline__ Top2 sweepf_top2(const float4* sq, const double2* sxy
 // ── far queries: a box hierarchy over the sort order ─────────────────────────────────────────────────
 // A walk visits every point whose key lies within the bound of the query's key: a query that is metres from every
 // target point (a pair started from a wrong pre-alignment, a rotation far from the right one) walks most of the
-// cloud — ~1 400 candidates instead of ~10 — and a wave waits for its longest lane.  So a walk that has taken
-// SWEEP_FAR_ROUNDS rounds gives up and the search is finished on a hierarchy of bounding boxes of the float32 images:
+// cloud — ~1 400 candidates instead of ~10 — and a wave waits for its longest lane.  So a walk that has taken a few
+// rounds (the caller's choice; what they meet is the descent's first bound) gives up and the search is finished on a
+// hierarchy of bounding boxes of the float32 images:
 // the leaves are BLOCKS of SWEEP_BLOCK consecutive sorted positions (in bearing order a contiguous piece of wall), every
 // inner node is the box of its two children — a complete binary tree in heap order over `leaves` (a power of two) blocks,
 // tree[1] the root, tree[leaves + b] the box of block b (min x, min y, max x, max y; an empty block is an empty box,

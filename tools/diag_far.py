@@ -22,7 +22,7 @@ b.run(); torch.cuda.synchronize()
 raw.icpmi_diag_read(dbg)
 d = list(dbg)
 print(f"sweepf_top2_far over the batch: {d[5]} calls, {d[6]} far scans; cycles per call: query setup {d[0]/max(d[5],1):.0f}, walk {d[1]/max(d[5],1):.0f}; "
-      f"per far scan: {d[3]/max(d[6],1):.0f} (box pass {d[2]/max(d[6],1):.0f})")
+      f"per far scan: {d[3]/max(d[6],1):.0f}")
 r = b.icp.results.cpu().numpy()[:B]
 cnt = b.icp.vox.cnt.cpu().numpy()
 N = cnt[0]
@@ -32,6 +32,6 @@ tot = r[:, 4] + r[:, 5] + r[:, 6] + r[:, 7]
 for i in np.argsort(-tot)[:10]:
     print(f"pair {i}: iters={int(r[i,14])} err={r[i,12]:.3f} total Mcycles={tot[i]/1e6:.2f} per-iter search={r[i,4]/it[i]:.0f} partials={r[i,5]/it[i]:.0f} lead={r[i,6]/it[i]:.0f} "
           f"apply={r[i,7]/it[i]:.0f} searches/row-iter={r[i,8]/(it[i]*N):.3f} far scans/search={(r[i,11] // 2**32)/max(r[i,8],1):.3f} "
-          f"blocks/far scan={(r[i,11] % 2**32)/max(r[i,11] // 2**32, 1):.1f} dir={int(dirs[1+i])} M={cnt[1+i]}")
+          f"dir={int(dirs[1+i])} M={cnt[1+i]}")
 bad = r[:, 12] >= 0.05
 print("bad pairs:", bad.sum(), "median total Mcycles bad", np.median(tot[bad]) / 1e6, "good", np.median(tot[~bad]) / 1e6)
