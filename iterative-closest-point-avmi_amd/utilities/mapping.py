@@ -8,6 +8,8 @@ and cell values are bit-identical to the NumPy implementation.
 """
 import ctypes as C
 
+import math
+
 import numpy as np
 import torch
 
@@ -121,7 +123,7 @@ class OccupancyGrid2D:
         st[2].record()
         rows = h[:n + 1]
         self._off1[1] = n
-        self._apply(st[1][:1], st[1][1:n + 1], self._off1, None, self._box_of(rows.min(axis=0), rows.max(axis=0)))
+        self._apply(st[1][:1], st[1][1:n + 1], self._off1, None, self._box_of(*_minmax_rows(rows)))
 
     def _stage(self, rows):
         """(pinned host rows, device rows, event of the last copy out of the host rows) — two sets used in turn."""
@@ -164,7 +166,7 @@ class OccupancyGrid2D:
             if host is not None and not isinstance(origins, torch.Tensor):       # everything is on the host: no read-back
                 o_host = np.asarray(origins, dtype=np.float64).reshape(S, 2)
                 both = np.vstack([o_host, host])
-                box = self._box_of(both.min(axis=0), both.max(axis=0))
+                box = self._box_of(*_minmax_rows(both))
                 # A long trajectory in one call: the box of all scans is far larger than any scan's reach, and the tile
                 # pass of the library enumerates the tiles of the box per scan.  Consecutive scans lie close together, so
                 # the replay goes down in pieces of _REPLAY_PIECE scans, each with its own box (same order, same result).
@@ -175,7 +177,7 @@ class OccupancyGrid2D:
                             continue
                         piece = np.vstack([o_host[c0:c1], host[off[c0]:off[c1]]])
                         self._apply(org[c0:c1], packed[off[c0]:off[c1]], off[c0:c1 + 1] - off[c0], rows,
-                                    self._box_of(piece.min(axis=0), piece.max(axis=0)))
+                                    self._box_of(*_minmax_rows(piece)))
                     return
         self._apply(org, packed, off, rows, box)
 
@@ -196,13 +198,15 @@ class OccupancyGrid2D:
         return self._box_of(lo_hi[0], lo_hi[1])
 
     def _box_of(self, lo, hi):
-        lo_hi = np.array([lo, hi], dtype=np.float64)
-        if not np.isfinite(lo_hi).all():
+        # four scalars: plain float arithmetic (the same IEEE operations as the array expression, a fifth of its time —
+        # this runs once per live scan)
+        x0, y0, x1, y1 = float(lo[0]), float(lo[1]), float(hi[0]), float(hi[1])
+        if not (math.isfinite(x0) and math.isfinite(y0) and math.isfinite(x1) and math.isfinite(y1)):
             return None                                         # a NaN / inf coordinate somewhere: no promise
-        mn = np.array([self.min_x, self.min_y])
-        c = np.floor((lo_hi - mn) / self.resolution)            # same expression as the cell index, monotone in the coordinate
-        c = np.clip(c, -2.0 ** 29, 2.0 ** 29)
-        return np.array([c[0, 0] - 1, c[0, 1] - 1, c[1, 0] + 1, c[1, 1] + 1], dtype=np.int32)
+        res, lim = self.resolution, 2.0 ** 29
+        # same expression as the cell index, monotone in the coordinate
+        c = [min(max(math.floor((v - m) / res), -lim), lim) for v, m in ((x0, self.min_x), (y0, self.min_y), (x1, self.min_x), (y1, self.min_y))]
+        return np.array([c[0] - 1, c[1] - 1, c[2] + 1, c[3] + 1], dtype=np.int32)
 
     def _apply(self, org, packed, off, rows=None, box=None):
         """org (S,2) and packed hits (sum N,2) are float64 device tensors; off is a host int32 array.
@@ -276,6 +280,13 @@ class OccupancyGrid2D:
 
     def save_npy(self, file_path):
         np.save(file_path, self.to_probability())
+
+
+def _minmax_rows(rows):
+    """(min, max) over the rows of an (n, 2) array — on a transposed copy: NumPy reduces axis 0 of a two-column array
+    with an inner loop of length two (90 us for a 2 048-beam scan), and the contiguous axis of the copy in 5."""
+    t = np.ascontiguousarray(rows.T)
+    return t.min(axis=1), t.max(axis=1)
 
 
 def bresenham_cells(segments):

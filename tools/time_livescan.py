@@ -39,3 +39,14 @@ if os.environ.get("RO_TIMES"):          # diagnostic library (-DRO_X_TIMES): cyc
     print(d[o[:12]])
     print("median total", np.median(d[:, 2]), "median select", np.median(d[:, 0]), "median walk", np.median(d[:, 1]))
     g._ws.zero_()
+
+# ... and the call slam.py:557 makes (NumPy origin and hits in), with the share of its host steps
+g.reset()
+print("host API update_scan (NumPy in):", bench.timed(torch, lambda: g.update_scan(org[0], hits[0])) * 1e6, "us per call")
+import timeit
+rows = np.vstack([org[:1], hits[0]])
+lo, hi = rows.min(axis=0), rows.max(axis=0)
+for name, fn in (("rows.min + rows.max", lambda: (rows.min(axis=0), rows.max(axis=0))), ("_box_of", lambda: g._box_of(lo, hi)),
+                 ("_apply (resident)", lambda: g._apply(d_org, d_hits, off, box=box))):
+    print(f"  {name}: {timeit.timeit(fn, number=2000) / 2000 * 1e6:.1f} us")
+torch.cuda.synchronize()
