@@ -296,3 +296,27 @@ def test_pair_lists_of_the_batched_run_icp_pair():
     assert len(clouds) == 4 and list(ps) == [0, 1] and list(pt) == [2, 3]
     with pytest.raises(ValueError):
         _pair_lists([a], [b, c])
+
+
+def test_cell_box_of_a_scan_matches_the_array_expression():
+    """The live update_scan takes the cell box of a scan on the host: min / max of the rows on a transposed copy and the
+    box in scalar arithmetic.  Both must equal the plain NumPy expressions they replace (same IEEE operations)."""
+    import types
+    from utilities import mapping
+    rng = np.random.default_rng(5)
+    grid = types.SimpleNamespace(min_x=-56.05, min_y=-60.0, resolution=0.05)
+    for trial in range(300):
+        scale = 10.0 ** rng.integers(-3, 11)
+        rows = rng.normal(size=(int(rng.integers(1, 400)), 2)) * scale
+        if trial % 50 == 7:
+            rows[rng.integers(0, len(rows)), rng.integers(0, 2)] = rng.choice([np.nan, np.inf, -np.inf])
+        lo, hi = mapping._minmax_rows(rows)
+        assert np.array_equal(lo, rows.min(axis=0), equal_nan=True) and np.array_equal(hi, rows.max(axis=0), equal_nan=True)
+        got = mapping.OccupancyGrid2D._box_of(grid, lo, hi)
+        lo_hi = np.array([rows.min(axis=0), rows.max(axis=0)])
+        if not np.isfinite(lo_hi).all():
+            assert got is None
+            continue
+        c = np.clip(np.floor((lo_hi - np.array([grid.min_x, grid.min_y])) / grid.resolution), -2.0 ** 29, 2.0 ** 29)
+        want = np.array([c[0, 0] - 1, c[0, 1] - 1, c[1, 0] + 1, c[1, 1] + 1], dtype=np.int32)
+        assert got.dtype == np.int32 and np.array_equal(got, want), trial
