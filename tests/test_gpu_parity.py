@@ -1494,13 +1494,14 @@ def test_run_icp_pair_batch_with_pairs_beyond_the_capacity_hint(uicp):
         assert np.array_equal(R[i], Ri[0]) and np.array_equal(t[i], ti[0]) and err[i] == ei[0] and info["iters"][i] == ii["iters"][0], i
 
 
-def test_build_then_smoke_in_one_process():
+def test_library_loaded_before_torch_then_smoke_in_one_process():
     """__graft_entry__.build() loads libicpmi.so before anything has imported torch; smoke() in the same process must
-    still run (the loader imports torch first, so that its HIP runtime is the only one in the process)."""
+    still run (the loader imports torch first, so that its HIP runtime is the only one in the process).  The child
+    does what build() does after compiling — load the library first — without running make."""
     import os
     import subprocess
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=repo,
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; import icpmi; icpmi.lib(); g.smoke()"], cwd=repo,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
