@@ -460,6 +460,52 @@ def gold_pose_graph():
     save("pose_graph", names=np.array(names), **out)
 
 
+# ── 12. pairs that never settle: all 150 iterations of a limit cycle of the point-to-line step (icp.py:177-223) ──
+def gold_icp_limit():
+    """Config-2 scan pairs of the bench's loop-closure batch that print "max iterations reached: iter=150" in the
+    reference; pair ids are kept so the tests regenerate the inputs from synth (seeded) and check their sums."""
+    srcs, tgts = synth.loop_closure_batch(64, seed0=1000)
+    cfg = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+    out, ids = {}, []
+    for i in range(64):
+        if len(ids) == 4:
+            break
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            R, t, err = ref_icp.ICP(srcs[i], tgts[i], **cfg)
+        if "max iterations reached: iter=150" not in buf.getvalue():
+            continue
+        ids.append(i)
+        out[f"p{i}__R"], out[f"p{i}__t"], out[f"p{i}__err"] = R, t, np.float64(err)
+        out[f"p{i}__src_sum"], out[f"p{i}__tgt_sum"] = srcs[i].sum(axis=0), tgts[i].sum(axis=0)
+        out[f"p{i}__printed"] = np.array(buf.getvalue())
+    save("icp_limit", ids=np.array(ids, dtype=np.int64), n_pairs=np.int64(64), seed0=np.int64(1000), **out)
+
+
+# ── 13. _run_icp_pair (slam.py:53-98): rotation search, then ICP from its result — the loop-closure path of slam.py:575-579 ──
+def gold_run_icp_pair():
+    sys.path.insert(0, REF)
+    ref_slam = _load("ref_slam", os.path.join(REF, "slam.py"))
+    B, seed0 = 96, 91000
+    srcs, tgts = synth.loop_closure_batch(B, seed0=seed0, shared_source=True, max_offset=3.0, max_yaw_deg=20.0)
+    icp_cfg = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+    feat_cfg = dict(rotation_voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
+    out, ids = {"src_sum": srcs[0].sum(axis=0)}, []
+    # registered (0, 30), converged to a wrong pose (60, 84), 150 iterations with a small error (18) and a large one (48, 28)
+    for i in (0, 18, 28, 30, 48, 60, 84):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            R, t, err = ref_slam._run_icp_pair(srcs[0], tgts[i], icp_cfg, feat_cfg, "rotation_search")
+        txt = buf.getvalue()
+        m = re.search(r"converged: iter=(\d+)", txt)
+        ids.append(i)
+        out[f"p{i}__R"], out[f"p{i}__t"], out[f"p{i}__err"] = R, t, np.float64(err)
+        out[f"p{i}__iters"] = np.int64(int(m.group(1)) + 1 if m else (150 if "max iterations reached" in txt else -1))
+        out[f"p{i}__tgt_sum"] = tgts[i].sum(axis=0)
+    save("run_icp_pair", ids=np.array(ids, dtype=np.int64), n_pairs=np.int64(B), seed0=np.int64(seed0),
+         icp_cfg=np.array([1e-10, 150, 0.04, 12]), feat_cfg=np.array([0.15, 1.5, 0.1]), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # python make_golden.py gold_submap_rotation ...
         for name in sys.argv[1:]:
@@ -476,3 +522,5 @@ if __name__ == "__main__":
     gold_rotation_search()
     gold_submap_rotation()
     gold_pose_graph()
+    gold_icp_limit()
+    gold_run_icp_pair()

@@ -275,3 +275,60 @@ def test_pose_graph_oracle_matches_reference():
         assert np.abs(out - z[f"{name}__out"]).max() < 1e-10, (name, np.abs(out - z[f"{name}__out"]).max())
         assert abs(opg.total_error(out, ei, ej, zz, om) - z[f"{name}__err"][1]) <= 1e-9 * max(1.0, z[f"{name}__err"][1])
     assert np.array_equal(opg.wrap(z["wrap_in"]), z["wrap_out"])
+
+
+# ── the two regimes the bench lives on, as the REFERENCE runs them (golden: make_golden.py gold_icp_limit / gold_run_icp_pair) ──
+def limit_cycle_pairs():
+    """(id, source, target, golden dict) of the config-2 loop-closure pairs that run all 150 iterations in the reference."""
+    from icpmi import synth
+    z = load_golden("icp_limit")
+    srcs, tgts = synth.loop_closure_batch(int(z["n_pairs"]), seed0=int(z["seed0"]))
+    for i in z["ids"]:
+        i = int(i)
+        assert np.array_equal(srcs[i].sum(axis=0), z[f"p{i}__src_sum"]) and np.array_equal(tgts[i].sum(axis=0), z[f"p{i}__tgt_sum"])
+        yield i, srcs[i], tgts[i], z
+
+
+def run_icp_pair_cases():
+    """(id, source, target, golden dict, icp_cfg, feat_cfg) of the 3 m / 20 degree candidates whose reference
+    _run_icp_pair result (slam.py:53-98) the fixture holds: registered, converged wrong, 150 iterations."""
+    from icpmi import synth
+    z = load_golden("run_icp_pair")
+    srcs, tgts = synth.loop_closure_batch(int(z["n_pairs"]), seed0=int(z["seed0"]), shared_source=True, max_offset=3.0, max_yaw_deg=20.0)
+    assert np.array_equal(srcs[0].sum(axis=0), z["src_sum"])
+    e, m, v, k = z["icp_cfg"]
+    icp_cfg = dict(error_threshold=float(e), max_iterations=int(m), voxel_size=float(v), method="point_to_line", normal_k=int(k))
+    rv, ac, af = z["feat_cfg"]
+    feat_cfg = dict(rotation_voxel_size=float(rv), angle_step_coarse=float(ac), angle_step_fine=float(af))
+    for i in z["ids"]:
+        i = int(i)
+        assert np.array_equal(tgts[i].sum(axis=0), z[f"p{i}__tgt_sum"])
+        yield i, srcs[0], tgts[i], z, icp_cfg, feat_cfg
+
+
+def test_icp_pairs_that_circle_until_max_iterations():
+    """150 iterations of a limit cycle of the point-to-line step (65 % of the bench's counted iterations): the
+    reference's transform after exactly those, icp.py:177-223."""
+    n = 0
+    for i, s, t, z in limit_cycle_pairs():
+        R, tt, err, info = oracle.icp(s, t, 1e-10, 150, 0.04, method="point_to_line", normal_k=12)
+        assert info["iters"] == 150 and info["status"] == oracle.MAXITER, i
+        assert "max iterations reached: iter=150" in str(z[f"p{i}__printed"])
+        assert rot_err(R, tt, z[f"p{i}__R"], z[f"p{i}__t"]) < 1e-9, i
+        assert abs(err - float(z[f"p{i}__err"])) < 1e-12, i
+        n += 1
+    assert n >= 3
+
+
+def test_run_icp_pair_rotation_search_then_icp():
+    """slam.py:53-98 with alignment_method "rotation_search": oracle.rotation_search -> oracle.icp from its result."""
+    seen = set()
+    for i, s, t, z, icp_cfg, feat_cfg in run_icp_pair_cases():
+        R0, t0, _ = oracle.rotation_search(s, t, feat_cfg["rotation_voxel_size"], feat_cfg["angle_step_coarse"], feat_cfg["angle_step_fine"])
+        R, tt, err, info = oracle.icp(s, t, icp_cfg["error_threshold"], icp_cfg["max_iterations"], icp_cfg["voxel_size"],
+                                      R_init=R0, t_init=t0, method="point_to_line", normal_k=icp_cfg["normal_k"])
+        assert info["iters"] == int(z[f"p{i}__iters"]), i
+        assert rot_err(R, tt, z[f"p{i}__R"], z[f"p{i}__t"]) < 1e-9, i
+        assert abs(err - float(z[f"p{i}__err"])) <= 1e-9 * max(1.0, err), i
+        seen.add((info["iters"] == 150, err < 0.08))
+    assert seen == {(False, True), (False, False), (True, True), (True, False)}       # every regime is in the fixture
