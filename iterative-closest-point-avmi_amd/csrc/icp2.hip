@@ -151,6 +151,12 @@ constexpr int CTRL_R = 0, CTRL_T = 4, CTRL_STOP = 6, CTRL_MP = 8, CTRL_MQ = 10;
 constexpr int CTRL_RT = 12, CTRL_TT = 16, CTRL_ERR = 18, CTRL_PREV = 19, CTRL_DELTA = 20, CTRL_ITERS = 21, CTRL_STATUS = 22,
               CTRL_DOUBLES = 24;
 
+#ifndef ICP2_PK
+#define ICP2_PK 1               // searches of the filter instantiations by the packed float32 walk (sweep.hpp, round 4); 0: the round-2 walks
+#endif
+#ifndef ICP2_PK_MIN
+#define ICP2_PK_MIN 16          // searching lanes of a wave from which the packed walk is taken
+#endif
 #ifndef ICP2_PLAIN_ITERS
 #define ICP2_PLAIN_ITERS 2      // iterations that search the plain nearest neighbour before budgets are kept
 #endif
@@ -459,7 +465,11 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                 for (int s = 0; s < ICP2_SMAX; ++s)
                     if (srch[s]) {
                         double d2s;
-                        if constexpr (FILT) pos[s] = sweepf_nn(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], it < ICP2_PLAIN_CENTRED, d2s);
+                        if constexpr (FILT) {
+                            if (ICP2_PK && __popcll(__ballot(true)) >= ICP2_PK_MIN)
+                                pos[s] = sweepf_nn_pk(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], it < ICP2_PLAIN_CENTRED);
+                            else pos[s] = sweepf_nn(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], it < ICP2_PLAIN_CENTRED, d2s);
+                        }
                         else pos[s] = sweep_nn(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], it < ICP2_PLAIN_CENTRED, d2s);
                     }
             } else {
@@ -510,7 +520,13 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                             const FarSlot o = far_q[slot[s]];
                             t2.p1 = o.out.p1; t2.p2 = o.out.p2; t2.s1 = o.out.s1; t2.s2 = o.out.s1; t2.s3 = o.out.s3;
                         }
-                        else if constexpr (FILT) t2 = sweepf_top2(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], centred);
+                        else if constexpr (FILT) {
+                            // the packed walk costs a wave the same whether one lane searches or all do; the branching walk
+                            // is cheap while few do (its exact path is then rarely entered): chosen per wave by the count
+                            if (ICP2_PK && __popcll(__ballot(true)) >= ICP2_PK_MIN)
+                                t2 = sweepf_top2_pk(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], centred);
+                            else t2 = sweepf_top2(lds_sq, sxy, filt, M, dir, uabs, px[s], py[s], pos[s], centred);
+                        }
                         else t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], centred);
                         pos[s] = t2.p1; pos2[s] = t2.p2;
                         const double d1 = sqrt(t2.s1), d3 = sqrt(t2.s3);

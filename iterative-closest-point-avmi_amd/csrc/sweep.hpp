@@ -637,6 +637,196 @@ __device__ __forceinline__ Top2 sweepf_top2(const float4* sq, const double2* sxy
     return t;
 }
 
+// ── packed walks: the whole walk in float32, exact arithmetic only for the listed survivors (round 4) ─
+// In the walks above a round is cheap while both candidates are rejected (24 vector instructions) — but the 64 lanes of
+// a wave share one instruction stream, and in nearly every round SOME lane has a candidate that passes the filter: the
+// wave then runs the exact float64 evaluation, the tie test and the new bounds (60-70 instructions) for that round.
+// Measured (round 4): the first top-two search of a batch — proof windows of ~9 candidates for the slowest of 64 lanes —
+// cost more than the unseeded first search.  So here the walk never leaves float32 and has no branch but its loop:
+// every candidate's filter value s32 = fma(dx, dx, dy * dy) (>= 0) is PACKED with its sorted position into one word,
+// (bits(s32) & ~0x7FF) | position (targets of at most 2 048 points; non-negative floats order like their bits), and the
+// K smallest words are kept in registers by integer v_med3_u32 / v_min_u32 — one instruction per list entry and
+// candidate, value and index together.  The window follows from the K-th word: the candidate behind it lies within
+//     B = sqrt(s32) (1 + 2^-22)^(1/2) + 3.42 e   of the query      (from |s32 - d^2| <= 2 sqrt2 e d + 2 e^2 + 2^-22 s32,
+// the bound of the filter section solved for d; e <= e15 / 1.5; the 11 index bits are set before the root is taken, so
+// the truncation only widens it), hence the K-th nearest true distance is at most B, and a side closes where the key
+// gap alone exceeds W(B) exactly as before.  After the walk, every candidate that can be among the K nearest has a filter
+// value of at most T(B) (the filter's guarantee d <= B => s32 <= T(B)); if the (K+1)-th word of the list lies above T(B)
+// the list holds them all, and only they are evaluated in float64 — (squared distance, original row) ascending, the
+// rule everywhere.  Otherwise (more candidates within the filter's resolution than the list holds: duplicates, lattices,
+// about one row in a thousand of an ordinary scan) or when the images are not finite-small, the lane falls back on the
+// exact walk above.  Same answers as the exhaustive scan by construction; the tests that hold the fast path to the
+// exhaustive kernel and the oracle bit for bit are the gate.
+constexpr unsigned SWEEP_PK_IDX = 0x7FFu;                              // positions below 2 048
+constexpr unsigned SWEEP_PK_NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ unsigned sweep_med3_u32(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned sweep_min_u32(unsigned a, unsigned b) { return a < b ? a : b; }
+
+template <int K>
+struct SweepPkList {
+    unsigned m[K];                                                     // ascending
+    __device__ __forceinline__ SweepPkList() {
+#pragma unroll
+        for (int k = 0; k < K; ++k) m[k] = SWEEP_PK_NONE;
+    }
+    __device__ __forceinline__ void offer(unsigned sp) {
+#pragma unroll
+        for (int k = K - 1; k > 0; --k) m[k] = sweep_med3_u32(m[k - 1], m[k], sp);
+        m[0] = sweep_min_u32(m[0], sp);
+    }
+};
+__device__ __forceinline__ unsigned sweep_pk(float s32, int i, bool in) {
+    return in ? ((__float_as_uint(s32) & ~SWEEP_PK_IDX) | (unsigned)i) : SWEEP_PK_NONE;
+}
+__device__ __forceinline__ float sweep_pk_floor(unsigned m) { return __uint_as_float(m & ~SWEEP_PK_IDX); }   // <= the filter value behind m
+
+struct SweepPkQuery : SweepFQuery {
+    float c25;                // 3.42 e + the float32 roundings of B
+    bool bad;                 // images not finite-small: the float32 values may overflow — the exact walk decides
+    __device__ __forceinline__ SweepPkQuery(const SweepF& f, int dir, double uabs, double qx, double qy) : SweepFQuery(f, dir, uabs, qx, qy) {
+        c25 = 2.5f * e15 + 1e-18f;
+        bad = !(fabsf(x) + fabsf(y) < 1e18f) || !(f.rt < 1e18f);
+    }
+    // float32 upper bound of the true distance of the candidate behind the packed word m (NaN while the list is not full:
+    // compares false everywhere, so nothing closes).  The fused multiply-adds are this bound's own (no reference arithmetic).
+    __device__ __forceinline__ float dist_bound(unsigned m) const {
+        return __builtin_fmaf(__builtin_amdgcn_sqrtf(__uint_as_float(m | SWEEP_PK_IDX)), 1.000002f, c25);
+    }
+    template <bool POLAR>
+    __device__ __forceinline__ float width(float B) const {
+        const float t = B * kw;
+        if (POLAR) {                                                   // asin t <= t + 0.3 t^3 on [0, 0.7]
+            const float w = __builtin_fmaf(t, __builtin_fmaf(0.3000004f, t * t, 1.000001f), mu);
+            return t <= 0.7f ? w : __builtin_inff();
+        }
+        return __builtin_fmaf(t, 1.000001f, mu);
+    }
+    __device__ __forceinline__ float threshold(float B) const {
+        const float b = B + e15;
+        return b * b * 1.000002f;
+    }
+};
+
+// The walk: every candidate of the window into the list.  lo / hi: the next candidate of either side.  A side takes its
+// candidate while the key gap is within W; W never grows (list entries only fall) and a side that stops stays on its
+// candidate, whose gap does not change — so a stopped side needs no flag, the same test keeps it stopped.  Bearing order
+// (POLAR): the sorted array is a circle — indices run on past either end (hi up to lo + m, the key shifted by 2 pi) until
+// every point has been visited once; the right side goes first when one point is left.
+// NB: the list entry that bounds the window (0: nearest neighbour, 2: the third distance); the entries behind it only tell
+// whether the list is complete.
+template <int K, int NB, bool POLAR>
+__device__ __forceinline__ void sweep_pk_walk(const float4* sq, const SweepPkQuery& fq, int lo, int hi, int m, int skip, SweepPkList<K>& L) {
+    float W = fq.width<POLAR>(fq.dist_bound(L.m[NB]));
+    const float ur = -fq.u, ul = fq.u, ur2 = 6.2831855f - fq.u, ul2 = fq.u + 6.2831855f;
+    for (;;) {
+        int hp = hi, lp = lo;
+        float o_r = ur, o_l = ul;
+        bool okr, okl;
+        if (POLAR) {
+            const bool wr = hi >= m, wl = lo < 0;
+            hp = wr ? hi - m : hi;
+            lp = wl ? lo + m : lo;
+            o_r = wr ? ur2 : ur;
+            o_l = wl ? ul2 : ul;
+            okr = hi - lo <= m;                                        // a point not visited yet is left
+        } else {
+            okr = hi < m;
+            okl = lo >= 0;
+        }
+        const float4 cr = sq[hp], cl = sq[lp];                         // sq[-1] and sq[m] exist (padding)
+        const bool inr = okr && !(cr.z + o_r > W);                     // key_right - key_q; else: everything further out is farther still
+        if (POLAR) okl = hi + (inr ? 1 : 0) - lo <= m;
+        const bool inl = okl && !(o_l - cl.z > W);                     // key_q - key_left
+        const sweep_v2f cx = {cr.x, cl.x}, cy = {cr.y, cl.y};
+        const sweep_v2f dx = fq.x - cx, dy = fq.y - cy;
+        const sweep_v2f s2 = __builtin_elementwise_fma(dx, dx, dy * dy);
+        L.offer(sweep_pk(s2.x, hp, inr && hp != skip));
+        L.offer(sweep_pk(s2.y, lp, inl && lp != skip));
+        if (!(inr || inl)) break;
+        W = fq.width<POLAR>(fq.dist_bound(L.m[NB]));
+        hi += inr ? 1 : 0;
+        lo -= inl ? 1 : 0;
+    }
+}
+
+template <int K, int NB>
+__device__ __forceinline__ void sweep_pk_search(const float4* sq, const SweepPkQuery& fq, int m, int seed, bool CENTRED, SweepPkList<K>& L) {
+    const bool seeded = seed >= 0 && seed < m;
+    int skip = -1;
+    // a seed on the other side of the seam at +-pi is no place to start from (the walk would cross the whole array)
+    const bool from_seed = seeded && !CENTRED && !(fq.polar && fabsf(sq[seed].z - fq.u) > 3.0f);
+    if (seeded && !from_seed) {                                        // the previous match bounds the window from the first round on
+        const float4 c = sq[seed];
+        const float ex = fq.x - c.x, ey = fq.y - c.y;
+        L.offer(sweep_pk(__builtin_fmaf(ex, ex, ey * ey), seed, true));
+        skip = seed;
+    }
+    const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);    // from the seed: it is the first candidate of the left side
+    if (fq.polar) sweep_pk_walk<K, NB, true>(sq, fq, h0 - 1, h0, m, skip, L);
+    else sweep_pk_walk<K, NB, false>(sq, fq, h0 - 1, h0, m, skip, L);
+}
+
+// sweepf_nn by the packed walk (seed, CENTRED as there; the squared distance is not returned: no caller of the plain
+// iterations uses it)
+__device__ __forceinline__ int sweepf_nn_pk(const float4* sq, const double2* sxy, const SweepF& f, int m, int dir, double uabs,
+                                            double qx, double qy, int seed, bool CENTRED) {
+    const SweepPkQuery fq(f, dir, uabs, qx, qy);
+    SweepPkList<3> L;
+    sweep_pk_search<3, 0>(sq, fq, m, seed, CENTRED, L);
+    const float T = fq.threshold(fq.dist_bound(L.m[0]));
+    int bpos = (int)(L.m[0] & SWEEP_PK_IDX);
+    const bool a2 = L.m[1] != SWEEP_PK_NONE && !(sweep_pk_floor(L.m[1]) > T);
+    const bool a3 = L.m[2] != SWEEP_PK_NONE && !(sweep_pk_floor(L.m[2]) > T);
+    if (a3 || fq.bad || L.m[0] == SWEEP_PK_NONE) {
+        double d2;
+        bpos = sweepf_nn(sq, sxy, f, m, dir, uabs, qx, qy, seed, CENTRED, d2);
+    } else if (a2) {                                                   // two candidates within the filter's resolution: exact, rows on a tie
+        const int i2 = (int)(L.m[1] & SWEEP_PK_IDX);
+        const double s1 = sweep_d2(qx, qy, sxy[bpos]), s2 = sweep_d2(qx, qy, sxy[i2]);
+        if (s2 < s1 || (s2 == s1 && sweepf_row(sq[i2]) < sweepf_row(sq[bpos]))) bpos = i2;
+    }
+    return bpos;
+}
+
+// sweepf_top2 by the packed walk
+__device__ __forceinline__ Top2 sweepf_top2_pk(const float4* sq, const double2* sxy, const SweepF& f, int m, int dir, double uabs,
+                                               double qx, double qy, int seed, bool CENTRED) {
+    const SweepPkQuery fq(f, dir, uabs, qx, qy);
+    SweepPkList<4> L;
+    sweep_pk_search<4, 2>(sq, fq, m, seed, CENTRED, L);
+    const float T = fq.threshold(fq.dist_bound(L.m[2]));
+    const bool a4 = L.m[3] != SWEEP_PK_NONE && !(sweep_pk_floor(L.m[3]) > T);
+    if (a4 || fq.bad || L.m[0] == SWEEP_PK_NONE) return sweepf_top2(sq, sxy, f, m, dir, uabs, qx, qy, seed, CENTRED);
+    // the three listed candidates in float64, ordered by (squared distance, original row)
+    double s[3];
+    int p[3], r[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool have = L.m[k] != SWEEP_PK_NONE;
+        p[k] = have ? (int)(L.m[k] & SWEEP_PK_IDX) : -1;
+        const int j = have ? p[k] : 0;
+        s[k] = have ? sweep_d2(qx, qy, sxy[j]) : __builtin_inf();
+        r[k] = have ? sweepf_row(sq[j]) : 0x7fffffff;
+    }
+#define ICPMI_CS(a, b)                                                                              \
+    do {                                                                                            \
+        const bool sw = s[b] < s[a] || (s[b] == s[a] && r[b] < r[a]);                              \
+        const double sa = sw ? s[b] : s[a], sb = sw ? s[a] : s[b];                                  \
+        const int pa = sw ? p[b] : p[a], pb = sw ? p[a] : p[b], ra = sw ? r[b] : r[a], rb = sw ? r[a] : r[b]; \
+        s[a] = sa; s[b] = sb; p[a] = pa; p[b] = pb; r[a] = ra; r[b] = rb;                           \
+    } while (0)
+    ICPMI_CS(0, 1); ICPMI_CS(1, 2); ICPMI_CS(0, 1);
+#undef ICPMI_CS
+    Top2 t;
+    t.p1 = p[0]; t.p2 = p[1]; t.s1 = s[0]; t.s2 = s[1]; t.s3 = s[2];
+    return t;
+}
+
 // ── far queries: a box hierarchy over the sort order ─────────────────────────────────────────────────
 // A walk visits every point whose key lies within the bound of the query's key: a query that is metres from every
 // target point (a pair started from a wrong pre-alignment, a rotation far from the right one) walks most of the
