@@ -332,23 +332,17 @@ def bench_run_icp_pair(torch, dist, synth, rank, world, red_dev, steps, warmup, 
     poses of the ICP-only legs (the like-for-like line); (3, 20) = SURVEY 8d / config.yaml:70.
     512 / world pairs per rank, the result all_gather inside the timed region."""
     from icpmi import _lib
-    from icpmi.dist import gather_results
-    from icpmi.prealign import RunIcpPairBatch
+    from icpmi.dist import RunIcpPairSharded
     n_total = 512
     B = n_total // world
     srcs, tgts = synth.loop_closure_batch(n_total, seed0=7000, shared_source=True, max_offset=max_offset, max_yaw_deg=max_yaw_deg)
-    mine = list(range(rank, n_total, world))
-    b = RunIcpPairBatch([srcs[0]] + [tgts[i] for i in mine], np.zeros(B, dtype=np.int32), np.arange(1, B + 1, dtype=np.int32),
-                        rotation_voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1, max_rows_hint=1024, **ICP_KW)
+    # the product's entry point for this path: candidate i on rank i mod world, one all_gather of the records (icpmi/dist.py)
+    feat = dict(rotation_voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
+    job = RunIcpPairSharded(srcs[0], tgts, ICP_KW, feat, max_rows_hint=1024)
+    b = job.batch
 
     def step(ev=None):
-        if ev is not None:
-            ev[0].record()
-        b.search.run()
-        if ev is not None:
-            ev[1].record()
-        res = b.icp.run(events=None if ev is None else (ev[1], ev[2]))
-        return gather_results(res[:B], n_total, rank, world) if world > 1 else res
+        return job.run(events=ev)
 
     def barrier():
         if world > 1:

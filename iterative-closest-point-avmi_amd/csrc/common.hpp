@@ -17,6 +17,9 @@ namespace icpmi {
 // ── process-wide state (state.hip): options read once, side streams of the library ───────────────────
 // option("NAME"): value of the ICPMI_NAME switch (environment at first use, icpmi_set_option later) or nullptr.
 const char* option(const char* name);
+// dyn_lds(kernel, bytes): the kernel's dynamic-LDS limit on the current device raised to at least `bytes` (state.hip: the
+// attribute is set when a launch needs more than any before it, not on every launch)
+hipError_t dyn_lds(const void* fn, size_t bytes);
 constexpr int ICPMI_SIDE_STREAMS = 3;
 struct Side {
     hipStream_t stream[ICPMI_SIDE_STREAMS] = {nullptr, nullptr, nullptr};

@@ -821,11 +821,9 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     } while (0)
 #define ICPMI_ICP2_GO2(TT, SS, L, F)                                                                                             \
     do {                                                                                                                         \
-        if (hipFuncSetAttribute((const void*)icp2_fused_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                                   \
+        if (dyn_lds((const void*)icp2_fused_kernel<TT, SS, L, F>, lds) != hipSuccess) return ICPMI_ERR_HIP;                      \
         if (pass == 1 && a.wide_list) {                     /* the listed pairs: few workgroups walking the list */              \
-            if (hipFuncSetAttribute((const void*)icp2_wide_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                                    (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                               \
+            if (dyn_lds((const void*)icp2_wide_kernel<TT, SS, L, F>, lds) != hipSuccess) return ICPMI_ERR_HIP;                   \
             hipStream_t ws = st;                            /* beside the second stage when the side stream is there */          \
             if (forked && hipStreamWaitEvent(side->stream[0], side->fork, 0) == hipSuccess) ws = side->stream[0];                 \
             icp2_wide_kernel<TT, SS, L, F><<<wide_grid, TT, lds, ws>>>(a);                                                       \
@@ -839,12 +837,10 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
         if (two_stage && pass == 0) {                       /* the parked pairs, all started together */                         \
             Icp2Args c = a;                                                                                                      \
             c.resume = 1; c.it_begin = a.it_limit; c.it_limit = 0x7fffffff;                                                      \
-            if (hipFuncSetAttribute((const void*)icp2_resume_kernel<TT, SS, L, F>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                    (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                               \
+            if (dyn_lds((const void*)icp2_resume_kernel<TT, SS, L, F>, lds) != hipSuccess) return ICPMI_ERR_HIP;                 \
             icp2_resume_kernel<TT, SS, L, F><<<stage2_grid, TT, lds, st>>>(c);                                                   \
             if (stage2_grid < n_pairs) {                    /* more parked pairs than workgroups: the rest of the list */         \
-                if (hipFuncSetAttribute((const void*)icp2_resume_rest_kernel<TT, SS, L, F>,                                      \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP; \
+                if (dyn_lds((const void*)icp2_resume_rest_kernel<TT, SS, L, F>, lds) != hipSuccess) return ICPMI_ERR_HIP;        \
                 icp2_resume_rest_kernel<TT, SS, L, F><<<256, TT, lds, st>>>(c, stage2_grid);                                     \
             }                                                                                                                    \
         }                                                                                                                        \
@@ -892,7 +888,14 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     double far_d2 = 1.0;
     if (const char* e = option("ICP2_FAR")) far_d2 = atof(e);
     const bool far_ok = have_ws && in_lds && want_filter && far_d2 > 0.0 && p->max_iterations > 2;
-    if (have_ws && (two_stage || T2 || far_ok)) {
+    // the far continuation's LDS: the filter layout + the box hierarchy (2 B per point at most) + a slot per row of its shape
+    // (every wave owns the stretch behind its own lanes, whatever the batch's source sizes).  Asked for BEFORE the first
+    // launch: without it (another ARCH than gfx950's 160 KB) no pair is parked for a kernel that could not start.
+    int far_cap = 64;
+    while (far_cap < max_tgt_n && far_cap < ICP2_FAR_POINTS) far_cap <<= 1;
+    const size_t far_lds = (size_t)far_cap * 50 + 32 + sizeof(FarSlot) * (size_t)(ICP2_FAR_THREADS * ICP2_FAR_SMAX);
+    const bool far_go = far_ok && dyn_lds((const void*)icp2_far_kernel, far_lds) == hipSuccess;
+    if (have_ws && (two_stage || T2 || far_go)) {
         unsigned char* w = (unsigned char*)workspace;
         a.st_xy = (double2*)w;
         a.st_pos = (int32_t*)(w + st_rows * 16);
@@ -904,7 +907,7 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
         a.far_count = a.list_count + 2;
         a.st_stride = max_src_n;
         if (!T2) { a.wide_list = nullptr; a.wide_count = nullptr; }
-        if (far_ok) a.far_d2 = far_d2;
+        if (far_go) a.far_d2 = far_d2;
         else { a.far_list = nullptr; a.far_count = nullptr; }
         if (hipMemsetAsync(a.list_count, 0, 3 * sizeof(int32_t), st) != hipSuccess) return ICPMI_ERR_HIP;
     }
@@ -939,14 +942,8 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     if (a.far_list) {                                       // after every first launch (the wide one has joined the stream)
         Icp2Args c = a;
         c.resume = 1; c.it_begin = 2; c.it_limit = 0x7fffffff; c.skip_over = 0; c.n_lo = -1; c.m_lo = 0;
-        int cap = 64;
-        while (cap < max_tgt_n && cap < ICP2_FAR_POINTS) cap <<= 1;
-        c.lds_points = cap;
-        // the filter layout + the box hierarchy (2 B per point at most) + a slot per row a workgroup can hold
-        const size_t lds = (size_t)cap * 50 + 32 + sizeof(FarSlot) * (size_t)(ICP2_FAR_THREADS * ICP2_FAR_SMAX);
-        if (hipFuncSetAttribute((const void*)icp2_far_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return ICPMI_ERR_HIP;
-        icp2_far_kernel<<<n_pairs < 256 ? n_pairs : 256, ICP2_FAR_THREADS, lds, st>>>(c);
+        c.lds_points = far_cap;
+        icp2_far_kernel<<<n_pairs < 256 ? n_pairs : 256, ICP2_FAR_THREADS, far_lds, st>>>(c);
     }
     ICPMI_LAUNCH_CHECK();
     return ICPMI_OK;

@@ -71,7 +71,7 @@ extern "C" int icpmi_nn_prepared_batch(const double* pts, const int32_t* off_dev
     int cap = 64;
     while (cap < max_tgt_n) cap <<= 1;
     const size_t lds = (size_t)cap * 20;
-    if (hipFuncSetAttribute((const void*)nn_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP;
+    if (dyn_lds((const void*)nn_sweep_kernel, lds) != hipSuccess) return ICPMI_ERR_HIP;
     for (int p0 = 0; p0 < n_pairs; p0 += 65535) {              // the pair index is the grid's y: slices of at most 65 535 pairs
         const int np = n_pairs - p0 < 65535 ? n_pairs - p0 : 65535;
         dim3 grid((max_src_n + NNS_THREADS - 1) / NNS_THREADS, np);

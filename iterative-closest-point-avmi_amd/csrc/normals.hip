@@ -163,7 +163,7 @@ extern "C" int icpmi_normals_2d_batch(const double* pts, const int32_t* off_dev,
         grows = (uint32_t*)((unsigned char*)workspace + (size_t)total_rows * 2 * 8);
     }
     const size_t lds = (size_t)lds_points * 12;
-    if (hipFuncSetAttribute((const void*)normals_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP;
+    if (dyn_lds((const void*)normals_kernel, lds) != hipSuccess) return ICPMI_ERR_HIP;
     normals_kernel<<<n_sel, NRM_THREADS, lds, (hipStream_t)stream>>>(pts, off_dev, cnt_dev, cloud_ids, k, out_normals, gkeys, grows, lds_points);
     ICPMI_LAUNCH_CHECK();
     return ICPMI_OK;

@@ -355,7 +355,7 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
 #define ICPMI_PREP_GO2(KKV, G)                                                                                          \
     do {                                                                                                                \
         const size_t lds = G ? lds_sep : lds_alias;                                                                     \
-        if (hipFuncSetAttribute((const void*)prep_targets_kernel<KKV, G>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+        if (dyn_lds((const void*)prep_targets_kernel<KKV, G>,                                                           \
                                 (int)lds) != hipSuccess) return ICPMI_ERR_HIP;                                          \
         prep_targets_kernel<KKV, G><<<n_sel * (KKV > 0 ? split : 1), PREP_THREADS, lds, st>>>(                          \
             pts, off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig, g_skey, g_dir, out_normals, lds_points, \
@@ -372,7 +372,7 @@ extern "C" int icpmi_prepare_targets_ex(const double* pts, const int32_t* off_de
         const int kcap = normal_k + 1 < max_n ? normal_k + 1 : max_n;
         const int sel_cap = (kcap + 63) / 64 * 64;
         const size_t lds_k = (size_t)sel_cap * 4 * (ANYK_THREADS / ICPMI_WAVE);
-        if (hipFuncSetAttribute((const void*)normals_anyk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k) != hipSuccess) return ICPMI_ERR_HIP;
+        if (dyn_lds((const void*)normals_anyk_kernel, lds_k) != hipSuccess) return ICPMI_ERR_HIP;
         int per_cloud = 2048 / n_sel;
         per_cloud = per_cloud < 1 ? 1 : (per_cloud > 256 ? 256 : per_cloud);
         normals_anyk_kernel<<<dim3(per_cloud, n_sel), ANYK_THREADS, lds_k, st>>>(off_dev, cnt_dev, cloud_ids, normal_k, g_sxy, g_snrm, g_sorig,

@@ -764,6 +764,8 @@ extern "C" int icpmi_rotation_search_batch(const double* pts, const int32_t* off
     // search order of the targets: a projection or, for scans in their sensor frame, the bearing (the library's estimate; any
     // order is exact for any query — RS_BATCH = "projection" keeps to the projections)
     const char* oe = option("RS_BATCH");
+    // a pair whose target is not among tgt_ids must report "no order" (status 2), not search whatever the workspace held
+    if (hipMemsetAsync(prepared + (size_t)total_rows * 40, 0xFF, (size_t)n_clouds * sizeof(int32_t), st) != hipSuccess) return ICPMI_ERR_HIP;
     rc = icpmi_prepare_targets_ex(vox, off_dev, off_host, cnt, tgt_ids, nullptr, tgt_ids ? n_tgt_ids : n_clouds, n_clouds, total_rows, max_n, -1,
                                   nullptr, prepared, prepared_bytes, oe && oe[0] == 'p' ? 0 : 1, stream);
     if (rc != ICPMI_OK) return rc;
@@ -785,7 +787,7 @@ extern "C" int icpmi_rotation_search_batch(const double* pts, const int32_t* off
     const char* e = option("RS_BATCH");
     a.prune = e && e[0] == 'f' ? 0 : 1;                                 // "full": every angle scored exactly
     const size_t lds = (size_t)cap * 48 + 32 + 32 * (size_t)sweepf_tree_leaves(cap);
-    if (hipFuncSetAttribute((const void*)rotation_search_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    if (dyn_lds((const void*)rotation_search_batch_kernel, lds) != hipSuccess)
         return ICPMI_ERR_HIP;
     rotation_search_batch_kernel<<<n_pairs, RSB_THREADS, lds, st>>>(a);
     ICPMI_LAUNCH_CHECK();

@@ -10,7 +10,12 @@
 //    records; every caller stream of a device shares these streams (calls from several streams overlap their side
 //    work only as far as the side streams differ).  icpmi_shutdown destroys them.
 //
-// Nothing else in the library outlives a call: no allocations, no caches, no handles.
+//  * kernel attributes: the largest dynamic-LDS size asked of a kernel on a device is remembered (dyn_lds), so that
+//    hipFuncSetAttribute is called when a launch needs more than any before it, not on every launch (it cost the
+//    0.2 ms single-pair path several microseconds of host time per launch).  The attribute lives in the HIP runtime;
+//    this is a mirror of what was set, nothing to destroy.
+//
+// Nothing else in the library outlives a call: no allocations, no handles.
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -49,6 +54,26 @@ const char* option(const char* name) {
     o.load();
     const auto it = o.values.find(strip_prefix(name));
     return it == o.values.end() ? nullptr : it->second.c_str();
+}
+
+struct LdsAttr {
+    std::mutex mu;
+    std::map<std::pair<const void*, int>, size_t> granted;
+};
+static LdsAttr& lds_attr() { static LdsAttr a; return a; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of kernel `fn` on the current device raised to at least `bytes`
+hipError_t dyn_lds(const void* fn, size_t bytes) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    LdsAttr& a = lds_attr();
+    std::lock_guard<std::mutex> g(a.mu);
+    size_t& have = a.granted[std::make_pair(fn, dev)];
+    if (bytes <= have) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
 }
 
 struct SideState {

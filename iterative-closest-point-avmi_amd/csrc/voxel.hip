@@ -389,10 +389,10 @@ extern "C" int icpmi_voxel_downsample_batch(const double* pts, const int32_t* of
         // 32 768 clouds); a lone cloud finishes sooner with 1 024 threads.
         const int vox_threads = n_clouds > 256 ? 512 : VOX_THREADS;
         if (dim == 2) {
-            if (hipFuncSetAttribute((const void*)voxel_small_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP;
+            if (dyn_lds((const void*)voxel_small_kernel<2>, lds) != hipSuccess) return ICPMI_ERR_HIP;
             voxel_small_kernel<2><<<n_clouds, vox_threads, lds, st>>>(pts, off_dev, voxel_size, out_pts, out_cnt);
         } else {
-            if (hipFuncSetAttribute((const void*)voxel_small_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ICPMI_ERR_HIP;
+            if (dyn_lds((const void*)voxel_small_kernel<3>, lds) != hipSuccess) return ICPMI_ERR_HIP;
             voxel_small_kernel<3><<<n_clouds, vox_threads, lds, st>>>(pts, off_dev, voxel_size, out_pts, out_cnt);
         }
         ICPMI_LAUNCH_CHECK();

@@ -105,6 +105,111 @@ def icp_batch_sharded(sources, targets, error_threshold, max_iterations, voxel_s
     return gather_results(local, n, rank, world, group)
 
 
+class RunIcpPairSharded:
+    """The loop-closure matching of slam.py:575-597 across the ranks of the process group: candidate i of ONE current scan
+    goes to rank ``i mod world``; every rank runs ``_run_icp_pair`` (slam.py:53-98: rotation search, then ICP from its
+    result — ``icpmi.prealign.RunIcpPairBatch``, one chain of launches) on its share, one all_gather of the 128-byte result
+    records follows, and ``first_accepted`` takes the FIRST candidate (in candidate order, as the reference's loop does)
+    whose error is below the gate.  The candidates stay resident: ``run()`` may be repeated.
+
+    ``solver(source, target_list) -> [k, RES_DOUBLES] tensor`` replaces the local GPU batch (the CPU tests inject the
+    oracle there).  Slot 8 of a gathered record (unused by 2-D results) carries the status of the pair's rotation search, so
+    that every rank knows which candidates fell outside the on-chip search's capacity: their owners redo them through the
+    single-pair entries (same numbers) and the records are gathered once more — all ranks take part, none has to be told."""
+    SEARCH_STATUS = 8
+
+    def __init__(self, source, targets, icp_cfg=None, feat_cfg=None, group=None, max_rows_hint=0, solver=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.n = len(targets)
+        self.mine = shard(self.n, self.rank, self.world)
+        self.source = source
+        self.targets = [targets[i] for i in self.mine]
+        self.icp_cfg, self.feat_cfg = dict(icp_cfg or {}), dict(feat_cfg or {})
+        self.solver = solver
+        self.batch = None
+        self.gathered = None
+        if solver is None and len(self.mine):
+            from .prealign import RunIcpPairBatch
+            k = len(self.mine)
+            c, f = self.icp_cfg, self.feat_cfg
+            self.batch = RunIcpPairBatch([source] + self.targets, np.zeros(k, dtype=np.int32), np.arange(1, k + 1, dtype=np.int32),
+                                         error_threshold=c.get("error_threshold", 1e-7), max_iterations=c.get("max_iterations", 100),
+                                         voxel_size=c.get("voxel_size", 0.06), method=c.get("method", "point_to_line"),
+                                         normal_k=c.get("normal_k", 10), rotation_voxel_size=f.get("rotation_voxel_size", 0.3),
+                                         angle_step_coarse=f.get("angle_step_coarse", 2.0), angle_step_fine=f.get("angle_step_fine", 0.2),
+                                         max_rows_hint=max_rows_hint)
+
+    def _local(self, events=None):
+        k = len(self.mine)
+        if self.solver is not None:
+            return self.solver(self.source, self.targets)
+        if k == 0:
+            return torch.zeros((0, _lib.RES_DOUBLES), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+        if events is not None:
+            events[0].record()
+        self.batch.search.run()
+        res = self.batch.icp.run(events=None if events is None else (events[1], events[2]))[:k]
+        res[:, self.SEARCH_STATUS] = self.batch.search.records[:k, 11]          # device-side copy: rides on the gather
+        return res
+
+    def run(self, events=None, force_collective=False):
+        """Enqueue the local chain and the gather; returns the [n, RES_DOUBLES] records in candidate order (device tensor
+        under nccl, no host round trip).  events: optional 3 torch events — before the search, between search and ICP half,
+        after the ICP half."""
+        self.gathered = gather_results(self._local(events), self.n, self.rank, self.world, self.group, force_collective)
+        return self.gathered
+
+    def results(self):
+        """(R [n,2,2], t [n,2], err [n], info) of the last run on the host (synchronises); candidates whose rotation search
+        fell outside the on-chip capacity are redone by their owners and gathered again."""
+        from .batch import unpack_results
+        res = self.gathered
+        over = torch.nonzero(res[:, self.SEARCH_STATUS] == 2.0).reshape(-1).cpu().numpy() if self.solver is None else np.empty(0, dtype=np.int64)
+        if len(over):
+            k = len(self.mine)
+            if self.batch is not None:
+                fixed = torch.from_numpy(np.ascontiguousarray(_pack_results(*self.batch.unpack()))).to(res.device)
+            else:
+                fixed = torch.zeros((0, _lib.RES_DOUBLES), dtype=torch.float64, device=res.device)
+            res = gather_results(fixed[:k], self.n, self.rank, self.world, self.group)
+            self.gathered = res
+        host = res.cpu().numpy().copy()
+        host[:, self.SEARCH_STATUS] = 0.0
+        return unpack_results(host, 2)
+
+    def first_accepted(self, error_accept):
+        """slam.py:582-597 on the gathered records: index of the first candidate with error < error_accept, or -1."""
+        return first_accepted(self.gathered, error_accept)
+
+
+def _pack_results(R, t, err, info):
+    res = np.zeros((len(err), _lib.RES_DOUBLES))
+    d = R.shape[1]
+    res[:, _lib.RES_R:_lib.RES_R + d * d] = R.reshape(len(err), d * d)
+    res[:, _lib.RES_T:_lib.RES_T + d] = t
+    res[:, _lib.RES_ERR] = err
+    res[:, _lib.RES_DELTA] = info["delta"]
+    res[:, _lib.RES_ITERS] = info["iters"]
+    res[:, _lib.RES_STATUS] = info["status"]
+    return res
+
+
+def run_icp_pair_batch_sharded(source, targets, icp_cfg=None, feat_cfg=None, error_accept=None, group=None, solver=None):
+    """``_run_icp_pair(source, targets[i], icp_cfg, feat_cfg, "rotation_search")`` for every candidate i (slam.py:575-579),
+    the candidates sharded over the ranks of the process group -> (R [n,2,2], t [n,2], err [n], info) on every rank, with
+    ``info["first_accepted"]`` = the candidate slam.py:582-597 would accept (first with err < error_accept; -1: none) when
+    a gate is given.  Same configuration keys and defaults as the reference."""
+    job = RunIcpPairSharded(source, targets, icp_cfg, feat_cfg, group=group, solver=solver)
+    job.run()
+    R, t, err, info = job.results()
+    if error_accept is not None:
+        ok = np.flatnonzero(err < error_accept)
+        info["first_accepted"] = int(ok[0]) if len(ok) else -1
+    return R, t, err, info
+
+
 # ── sharded map replay (SURVEY §8e): every rank replays all scans into its own band of rows ──────────────
 def _as_tensor(a):
     return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))

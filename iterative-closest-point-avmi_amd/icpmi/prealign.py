@@ -22,6 +22,7 @@ from .batch import CloudSet, IcpBatch, _ptr, _stream, require_gpu, unpack_result
 
 REC_DOUBLES = 16
 ST_OK, ST_FEW, ST_CAPACITY, ST_NO_FINE = 0, 1, 2, 3
+RSB_MAX_ANGLES = 1024          # angles per sweep the batched kernel tabulates (csrc/rotsearch.hip)
 
 
 def arange_rows(lo, hi, step):
@@ -105,6 +106,7 @@ class RotationSearchBatch:
         self.steps = (angle_step_coarse, angle_step_fine)
         self.tables = AngleTables.get(dev, angle_step_coarse, angle_step_fine)
         self.max_rows_hint = int(max_rows_hint)
+        self.too_many_angles = len(self.tables.coarse) > RSB_MAX_ANGLES or self.tables.max_fine > RSB_MAX_ANGLES
         self.records = torch.zeros((max(self.B, 1), REC_DOUBLES), dtype=torch.float64, device=dev)
         self.init = init if init is not None else torch.zeros((max(self.B, 1), 6), dtype=torch.float64, device=dev)
         need = L.icpmi_rotation_search_batch_workspace_bytes(self.raw.total_rows, self.raw.n_clouds, self.raw.max_n)
@@ -113,6 +115,10 @@ class RotationSearchBatch:
     def run(self):
         t = self.tables
         mf = t.max_fine
+        if self.too_many_angles:                   # icpmi_rotation_search_batch would answer ICPMI_ERR_UNSUPPORTED
+            self.records.zero_()
+            self.records[:, 11] = ST_CAPACITY      # results() searches such pairs one by one: same numbers
+            return self.records
         check(_lib.lib().icpmi_rotation_search_batch(
             _ptr(self.raw.pts), _ptr(self.raw.off), self.raw.off_host.ctypes.data_as(C.c_void_p), self.raw.n_clouds,
             _ptr(self.tgt_ids), len(self.tgt_ids), _ptr(self.pair_src), _ptr(self.pair_tgt), self.B, self.voxel_size,
@@ -196,6 +202,14 @@ class RunIcpPairBatch:
         self.B = B
 
     def run(self, events=None):
+        if self.search.too_many_angles:
+            # more angles than the batched kernel tabulates (a step below ~0.36 degrees): every pair is searched by the
+            # single-pair entry, as pairs beyond the capacity hint are — same numbers
+            self.search.records.zero_()
+            self.search.records[:, 11] = ST_CAPACITY
+            if events is not None:
+                events[0].record(); events[1].record()
+            return self.icp.results
         self.search.run()
         return self.icp.run(events=events)
 
@@ -204,6 +218,8 @@ class RunIcpPairBatch:
         with the single-pair search's result as their start."""
         rec = self.search.records.cpu().numpy()[:self.B]
         res = self.icp.results.cpu().numpy()[:self.B].copy()
+        if (rec[:, 11].astype(np.int64) == ST_NO_FINE).any():
+            raise ValueError("attempt to get argmin of an empty sequence")          # features.py:231: np.argmin of an empty fine grid
         over = np.flatnonzero(rec[:, 11].astype(np.int64) == ST_CAPACITY)
         if len(over):
             from .batch import icp_pair

@@ -1242,6 +1242,27 @@ def test_rccl_world_of_one_gathers_results_and_bands(uicp):
             Ro, to, eo, io = oracle.icp(srcs[i], tgts[i], 1e-10, 30, 0.04, method="point_to_line", normal_k=12)
             r = res[i].cpu().numpy()
             assert int(r[14]) == io["iters"] and rot_err(r[:4].reshape(2, 2), r[9:11], Ro, to) < FRO_TOL
+        # the loop-closure matching as slam.py:575-597 runs it, sharded (one rank here): rotation search + ICP per candidate,
+        # the records through the collective, first accepted candidate; one candidate above the search's capacity hint
+        from icpmi import prealign
+        srcs, tgts = synth.loop_closure_batch(9, seed0=91000, shared_source=True, max_offset=3.0, max_yaw_deg=20.0)
+        icp_cfg = dict(error_threshold=1e-10, max_iterations=150, voxel_size=0.04, method="point_to_line", normal_k=12)
+        feat_cfg = dict(rotation_voxel_size=0.15, angle_step_coarse=1.5, angle_step_fine=0.1)
+        job = idist.RunIcpPairSharded(srcs[0], tgts, icp_cfg, feat_cfg)
+        assert job.run(force_collective=True).is_cuda
+        R, t, err, info = job.results()
+        R1, t1, err1, info1 = prealign.run_icp_pair_batch(srcs[0], tgts, icp_cfg, feat_cfg)
+        assert np.array_equal(R, R1) and np.array_equal(t, t1) and np.array_equal(err, err1) and np.array_equal(info["iters"], info1["iters"])
+        ok = np.flatnonzero(err < 0.08)
+        assert job.first_accepted(0.08) == (int(ok[0]) if len(ok) else -1)
+        job = idist.RunIcpPairSharded(srcs[0], tgts, icp_cfg, feat_cfg, max_rows_hint=320)      # ~430 filtered rows > 320: status 2
+        job.run(force_collective=True)
+        assert (job.gathered[:, job.SEARCH_STATUS] == 2.0).all()
+        R2, t2, err2, info2 = job.results()
+        for i in range(9):
+            assert rot_err(R2[i], t2[i], R1[i], t1[i]) < FRO_TOL and int(info2["iters"][i]) == int(info1["iters"][i]), i
+        R3, t3, err3, info3 = idist.run_icp_pair_batch_sharded(srcs[0], tgts, icp_cfg, feat_cfg, error_accept=0.08)
+        assert np.array_equal(R3, R1) and info3["first_accepted"] == (int(ok[0]) if len(ok) else -1)
         torch.cuda.synchronize()
     finally:
         dist.destroy_process_group()
@@ -1577,3 +1598,45 @@ def test_far_pairs_that_never_settle_fast_exhaustive_oracle(uicp, method):
             assert abs(ef[i] - eo) <= 1e-9 * max(1.0, eo), (pre, i)
             at_limit += io["iters"] == maxit
         assert at_limit >= (3 if method == "point_to_line" else 0), (pre, at_limit)
+
+
+def test_run_icp_pair_batch_edges_of_the_angle_grids(uicp):
+    """(1) more angles per sweep than the batched kernel tabulates (a coarse step of 0.3 degrees: 1 200 angles)
+    takes the per-pair route instead of failing; (2) an empty fine grid (features.py:227-231: np.argmin of an empty
+    sequence) raises the reference's ValueError from unpack() too, not only from results()."""
+    from icpmi import prealign, synth
+    from utilities import features
+    features.VERBOSE = False
+    srcs, tgts = synth.loop_closure_batch(3, seed0=640, shared_source=True, max_offset=1.0, max_yaw_deg=10.0)
+    src, tgts = srcs[0][::2], [t[::2] for t in tgts]
+    icp_cfg = dict(error_threshold=1e-10, max_iterations=40, voxel_size=0.05, method="point_to_line", normal_k=10)
+    feat_cfg = dict(rotation_voxel_size=0.2, angle_step_coarse=0.3, angle_step_fine=0.05)
+    R, t, err, info = prealign.run_icp_pair_batch(src, tgts, icp_cfg, feat_cfg)
+    for i in range(3):
+        R0, t0, _ = features.rotation_search(src, tgts[i], 0.2, 0.3, 0.05)
+        Ro0, to0, _ = oracle.rotation_search(src, tgts[i], 0.2, 0.3, 0.05)
+        assert np.array_equal(R0, Ro0) and np.array_equal(t0, to0), i
+        Ro, to, eo, io = oracle.icp(src, tgts[i], 1e-10, 40, 0.05, R_init=Ro0, t_init=to0, method="point_to_line", normal_k=10)
+        assert int(info["iters"][i]) == io["iters"] and rot_err(R[i], t[i], Ro, to) < FRO_TOL, i
+    Rs, ts, ss = prealign.rotation_search_batch(src, tgts, 0.2, 0.3, 0.05)
+    assert np.array_equal(Rs[1], oracle.rotation_search(src, tgts[1], 0.2, 0.3, 0.05)[0])
+    with pytest.raises(ValueError, match="empty sequence"):
+        prealign.run_icp_pair_batch(src, tgts, icp_cfg, dict(rotation_voxel_size=0.2, angle_step_coarse=2.0, angle_step_fine=-0.2))
+    with pytest.raises(ValueError, match="empty sequence"):
+        prealign.rotation_search_batch(src, tgts, 0.2, 2.0, -0.2)
+
+
+def test_rotation_search_batch_pair_with_an_unlisted_target(uicp):
+    """a pair whose target cloud is not among tgt_ids has no search order: it reports status 2 (and the host
+    searches it through the single-pair entry) instead of walking whatever the workspace held."""
+    import ctypes as C
+    import torch
+    from icpmi import _lib, prealign, synth
+    from icpmi.batch import _ptr, _stream
+    a, b = synth.config2_pair(4)
+    srch = prealign.RotationSearchBatch([a, b, a[::2]], [0, 0], [1, 2], 0.15, 1.5, 0.1)
+    srch.ws.fill_(0x11)                                       # a "direction" of 0x11111111 would pass for garbage otherwise
+    srch.tgt_ids = torch.tensor([1], dtype=torch.int32, device=srch.ws.device)          # cloud 2 left out
+    srch.run()
+    rec = srch.records.cpu().numpy()
+    assert int(rec[0, 11]) == 0 and int(rec[1, 11]) == 2

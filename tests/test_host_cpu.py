@@ -132,6 +132,61 @@ def test_sharded_batch_gloo_world2(tmp_path):
     assert "GLOO_OK 2" in r.stdout
 
 
+RUN_ICP_PAIR_WORKER = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {pkg!r})
+import oracle
+from icpmi import dist as idist, synth, _lib
+
+ICP = dict(error_threshold=1e-10, max_iterations=40, voxel_size=0.1, method="point_to_line", normal_k=8)
+FEAT = dict(rotation_voxel_size=0.3, angle_step_coarse=6.0, angle_step_fine=1.0)
+
+def solver(src, tgts):          # slam.py:53-98 with the oracle: rotation search, then ICP from its result
+    out = np.zeros((len(tgts), _lib.RES_DOUBLES))
+    for i, t in enumerate(tgts):
+        R0, t0, _ = oracle.rotation_search(src, t, FEAT["rotation_voxel_size"], FEAT["angle_step_coarse"], FEAT["angle_step_fine"])
+        R, tt, err, info = oracle.icp(src, t, 1e-10, 40, 0.1, R_init=R0, t_init=t0, method="point_to_line", normal_k=8)
+        out[i, :4] = R.ravel(); out[i, 9:11] = tt; out[i, 12] = err
+        out[i, 13] = info["delta"]; out[i, 14] = info["iters"]; out[i, 15] = info["status"]
+    return torch.from_numpy(out)
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+srcs, tgts = synth.loop_closure_batch(7, seed0=311, shared_source=True, max_offset=2.0, max_yaw_deg=15.0)
+src = srcs[0][::4]; tgts = [t[::4] for t in tgts]
+job = idist.RunIcpPairSharded(src, tgts, ICP, FEAT, solver=solver)
+assert list(job.mine) == list(range(rank, 7, world))
+res = job.run()
+full = solver(src, tgts)                                   # every candidate locally, in candidate order
+assert res.shape == (7, _lib.RES_DOUBLES) and torch.equal(res, full), rank
+err = full[:, 12].numpy()
+gate = float(np.sort(err)[2]) * 1.0000001                  # three candidates pass: the FIRST in candidate order wins
+want = int(np.flatnonzero(err < gate)[0])
+assert job.first_accepted(gate) == want and job.first_accepted(0.0) == -1
+R, t, e, info = idist.run_icp_pair_batch_sharded(src, tgts, ICP, FEAT, error_accept=gate, solver=solver)
+assert info["first_accepted"] == want and np.array_equal(e, err) and np.array_equal(R.reshape(7, 4), full[:, :4].numpy())
+assert np.array_equal(info["iters"], full[:, 14].numpy().astype(np.int64))
+dist.barrier()
+if rank == 0:
+    print("GLOO_RUN_ICP_PAIR_OK", world)
+dist.destroy_process_group()
+'''
+
+
+def test_sharded_run_icp_pair_gloo_world2(tmp_path):
+    """icpmi.dist.RunIcpPairSharded / run_icp_pair_batch_sharded (slam.py:575-597 over ranks): candidates interleaved over two
+    gloo ranks, the oracle injected as the local solver; gathered records in candidate order, first accepted candidate."""
+    script = tmp_path / "worker.py"
+    script.write_text(RUN_ICP_PAIR_WORKER.format(repo=REPO, pkg=PKG))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29733", str(script)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "GLOO_RUN_ICP_PAIR_OK 2" in r.stdout
+
+
 def test_row_bands_cover_and_balance():
     import torch
     from icpmi import dist as idist, synth
