@@ -304,12 +304,25 @@ def test_bench_refuses_stale_pmc_traffic(tmp_path, monkeypatch):
     f = tmp_path / "pmc.json"
     f.write_text(json.dumps(doc))
     monkeypatch.setattr(bench, "PMC_TRAFFIC", str(f))
-    assert bench.pmc_traffic("icp2_", 64)[0] == 123
-    assert bench.pmc_traffic("icp2_", 65)[0] is None
+    assert bench.pmc_traffic(64)[0] == 123
+    assert bench.pmc_traffic(65)[0] is None
     doc["csrc_sha256"] = "0" * 16
     f.write_text(json.dumps(doc))
-    t, why = bench.pmc_traffic("icp2_", 64)
+    t, why = bench.pmc_traffic(64)
     assert t is None and "stale" in why
+    # the vector-issue roofline of a batch comes from the committed SQ-counter summary the same way
+    k = "void icpmi::icp2_fused_kernel<512, 2, true, true> [64 workgroups]"
+    mix = {"csrc_sha256": sig, "kernels": {k: {"SQ_ACTIVE_INST_VALU": 6.4e6, "SQ_BUSY_CYCLES": 1.0e6,
+                                               "derived": {"valu_issue_frac": 0.8, "active_lanes_per_valu_instruction": 44.0}}}}
+    g = tmp_path / "mix.json"
+    g.write_text(json.dumps(mix))
+    monkeypatch.setattr(bench, "PMC_MIX", str(g))
+    issue, src = bench.pmc_issue(64)
+    assert abs(issue["frac"] - 6.4e6 * 4 / (1024 * 1.0e6 / 32)) < 1e-4 and "same csrc" in src
+    mix["csrc_sha256"] = "0" * 16
+    g.write_text(json.dumps(mix))
+    assert bench.pmc_issue(64)[0] is None and "stale" in bench.pmc_issue(64)[1]
+    assert os.path.basename(bench.latest_profile("pmc_traffic.json")).startswith("r")
 
 
 def test_arange_rows_is_numpys_arange():

@@ -27,9 +27,15 @@ def collect(path):
 
 def main(a_csv, b_csv, keep):
     a, b = collect(a_csv), collect(b_csv)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     out = {"how": "rocprofv3 --kernel-trace --pmc <6 SQ counters> (two passes) -- python3 bench.py --steps 3 --warmup 1 "
                   "--no-cpu-baseline; values per dispatch, averaged over the dispatches of a kernel at one grid size; "
-                  "instruction counters count wave-level instructions",
+                  "instruction counters count wave-level instructions.  derived.valu_issue_frac = SQ_ACTIVE_INST_VALU "
+                  "(quad-cycles in which a SIMD issued a vector instruction, summed over the chip) x 4 / (1024 SIMDs x "
+                  "SQ_BUSY_CYCLES / 32 shader engines): the share of the chip's vector issue cycles the kernel used",
+           "csrc_sha256": bench.csrc_signature(),
            "kernels": {}}
     for k in sorted(a):
         if keep and not any(t in k for t in keep):
@@ -45,6 +51,8 @@ def main(a_csv, b_csv, keep):
             "branches_per_100_valu": round(100 * br / valu, 1) if valu else None,
             "active_lanes_per_valu_instruction": round(d["SQ_THREAD_CYCLES_VALU"] / d["SQ_ACTIVE_INST_VALU"], 1)
             if d.get("SQ_ACTIVE_INST_VALU") and d.get("SQ_THREAD_CYCLES_VALU") else None,
+            "valu_issue_frac": round(d["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * d["SQ_BUSY_CYCLES"] / 32.0), 4)
+            if d.get("SQ_ACTIVE_INST_VALU") and d.get("SQ_BUSY_CYCLES") else None,
             "fp64_add_mul_share_of_valu": round((d.get("SQ_INSTS_VALU_ADD_F64", 0) + d.get("SQ_INSTS_VALU_MUL_F64", 0)) / valu, 3)
             if valu else None}
         out["kernels"][k] = e

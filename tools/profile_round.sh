@@ -3,7 +3,7 @@
 # traffic passes (FETCH_SIZE, WRITE_SIZE: separate runs, --kernel-trace only) and the SQ instruction-mix passes.
 # Raw CSVs are summarised here and deleted (they exceed what gpurun copies back).  usage: tools/profile_round.sh rNN
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/profile_$TAG
 mkdir -p $OUT && cd /tmp && export TMPDIR=/tmp
@@ -20,5 +20,6 @@ python3 $R/tools/pmc_instruction_mix.py $(ls $OUT/mixa/*/*counter_collection.csv
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mixa $OUT/mixb
 # the bench line reads the traffic summary from profiles/ (and refuses one measured on other kernel sources)
 cp $OUT/${TAG}_pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json
+cp $OUT/${TAG}_pmc_instruction_mix.json $R/profiles/${TAG}_pmc_instruction_mix.json
 cd $R && python3 bench.py > $OUT/${TAG}_bench_line.json 2> $OUT/bench.err
 ls -la $OUT
