@@ -154,6 +154,9 @@ constexpr int CTRL_RT = 12, CTRL_TT = 16, CTRL_ERR = 18, CTRL_PREV = 19, CTRL_DE
 #ifndef ICP2_PK
 #define ICP2_PK 1               // searches of the filter instantiations by the packed float32 walk (sweep.hpp, round 4); 0: the round-2 walks
 #endif
+#ifndef ICP2_STAGE1_ITERS
+#define ICP2_STAGE1_ITERS 12    // iterations of the first stage of a large batch (launch_icp2)
+#endif
 #ifndef ICP2_PK_MIN
 #define ICP2_PK_MIN 16          // searching lanes of a wave from which the packed walk is taken
 #endif
@@ -868,7 +871,7 @@ int launch_icp2(const double* pts, const int32_t* off, const int32_t* cnt, const
     // against 0.65 ms).  About one pair
     // in thirteen of a loop-closure batch runs to the iteration limit; 12 iterations settle the others.
     // option ICP2_STAGES = 1 keeps one launch (experiments, and the test that both give the same bits).
-    constexpr int STAGE1_ITERATIONS = 12;                   // measured 6.12 / 5.42 / 5.36 / 5.38 / 5.39 ms at 8 / 10 / 12 / 14 / 16
+    constexpr int STAGE1_ITERATIONS = ICP2_STAGE1_ITERS;                   // measured 6.12 / 5.42 / 5.36 / 5.38 / 5.39 ms at 8 / 10 / 12 / 14 / 16
     const char* senv = option("ICP2_STAGES");
     const size_t st_rows = (size_t)n_pairs * (size_t)max_src_n;
     const size_t st_bytes = st_rows * 20 + (size_t)n_pairs * 12 + 64;

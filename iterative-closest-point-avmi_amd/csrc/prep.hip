@@ -31,7 +31,7 @@ __device__ __forceinline__ void prep_sort_regs(const double* __restrict__ P, int
         by_row[i] = k;
         v[e] = i < M ? ((k & ~ROW_MASK) | (uint64_t)i) : ~0ull;
     }
-    bitonic_sort_regs<uint64_t, E>(v, keys);                           // ends with a barrier: by_row is complete too
+    bitonic_sort_regs_fixed<uint64_t, E, PREP_THREADS>(v, keys);       // its LDS stages hold barriers: by_row is complete too
     int bad = 0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {

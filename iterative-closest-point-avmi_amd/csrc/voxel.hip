@@ -18,6 +18,10 @@
 
 #include "sort.hpp"
 
+#ifndef VOX_STOP_AFTER
+#define VOX_STOP_AFTER 0        // diagnostic variants only: leave the small kernel after a phase (1 bounds, 2 keys, 3 sort)
+#endif
+
 namespace icpmi {
 
 constexpr int VOX_THREADS = 1024;   // upper bound; the launcher picks 512 for large batches (loops use blockDim.x)
@@ -151,6 +155,9 @@ __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
 
     double mn[3], mx[3], ext[3];
     cloud_bounds<DIM>(P, n, mn, mx, dscratch);
+#if VOX_STOP_AFTER == 1
+    if (threadIdx.x == 0) out_cnt[c] = (int)mn[0]; return;
+#endif
     if (!key_extents<DIM>(mn, mx, voxel, ext)) { if (threadIdx.x == 0) out_cnt[c] = -1; return; }
     // (key, row) sorts as ONE integer key << row_bits | row when that fits: the sort is bound by LDS traffic,
     // and a 2 048-beam scan in a room needs ~18 + 11 bits
@@ -176,7 +183,14 @@ __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
                 uint32_t v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = packed((int)threadIdx.x * 4 + e);
-                bitonic_sort_regs<uint32_t, 4>(v, scratch);
+#if VOX_STOP_AFTER == 2
+                if (threadIdx.x == 0) out_cnt[c] = (int)(v[0] + v[1] + v[2] + v[3]); return;
+#endif
+                if (blockDim.x == 512) bitonic_sort_regs_fixed<uint32_t, 4, 512>(v, scratch);
+                else bitonic_sort_regs_fixed<uint32_t, 4, 1024>(v, scratch);
+#if VOX_STOP_AFTER == 3
+                if (threadIdx.x == 0) out_cnt[c] = (int)(v[0] + v[1] + v[2] + v[3]); return;
+#endif
                 __syncthreads();                                            // scratch reads of the last LDS stage are done
 #pragma unroll
                 for (int e = 0; e < 4; ++e) unpack((int)threadIdx.x * 4 + e, v[e]);
@@ -184,7 +198,8 @@ __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
                 uint32_t v[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) v[e] = packed((int)threadIdx.x * 2 + e);
-                bitonic_sort_regs<uint32_t, 2>(v, scratch);
+                if (blockDim.x == 512) bitonic_sort_regs_fixed<uint32_t, 2, 512>(v, scratch);
+                else bitonic_sort_regs_fixed<uint32_t, 2, 1024>(v, scratch);
                 __syncthreads();
 #pragma unroll
                 for (int e = 0; e < 2; ++e) unpack((int)threadIdx.x * 2 + e, v[e]);
