@@ -18,6 +18,9 @@
 
 #include "sort.hpp"
 
+#ifndef VOX_REGS
+#define VOX_REGS 1              // 0: the round-3 path (sorted words unpacked to LDS, voxel_finish) for the usual shape too
+#endif
 #ifndef VOX_STOP_AFTER
 #define VOX_STOP_AFTER 0        // diagnostic variants only: leave the small kernel after a phase (1 bounds, 2 keys, 3 sort)
 #endif
@@ -134,6 +137,94 @@ __device__ __forceinline__ void voxel_finish(const uint64_t* keys, const uint32_
     if (threadIdx.x == 0) *out_cnt = total;
 }
 
+// The usual shape — a 2 048-beam scan on 512 or 1 024 threads, keys and rows in one 32-bit word — from the sort to the
+// means on REGISTERS (round 4; before: the sorted words were unpacked to 12 B per element of LDS, every voxel head re-read
+// its neighbours' keys from there and fetched its members' points one dependent load after the other: a third of the
+// kernel).  After the sort thread t holds the sorted elements t E .. t E + E - 1: it fetches THEIR points at once (E
+// independent loads), finds the voxel heads among them from its own registers (the element before its first through
+// LDS), and a head adds up its run out of the thread's own registers; only a run that continues past the thread's last
+// element goes on through LDS and global memory.  Same sums in the same order: rows ascending inside a voxel.
+template <int DIM>
+__device__ __forceinline__ uint32_t vox_key32(const double* p, const double (&mn)[3], const uint32_t (&ext)[3], double voxel) {
+    uint32_t k = 0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) k = k * ext[d] + (uint32_t)(int)floor((p[d] - mn[d]) / voxel);   // every factor below 2^31 here
+    return k;
+}
+
+template <int DIM, int E, int THREADS>
+__device__ __forceinline__ void voxel_small_regs(const double* __restrict__ P, double* __restrict__ O, int n, double voxel,
+                                                 const double (&mn)[3], const double (&extd)[3], int row_bits, uint32_t* sorted,
+                                                 int* iscratch, int32_t* out_cnt) {
+    constexpr uint32_t PAD = 0xffffffffu;
+    const int tid = (int)threadIdx.x;
+    const uint32_t ext[3] = {(uint32_t)extd[0], (uint32_t)extd[1], (uint32_t)extd[2]};
+    const uint32_t row_mask = (1u << row_bits) - 1u;
+    uint32_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {                                    // rows e THREADS + t: coalesced; any start order sorts the same
+        const int i = e * THREADS + tid;
+        v[e] = i < n ? (vox_key32<DIM>(P + (size_t)i * DIM, mn, ext, voxel) << row_bits) | (uint32_t)i : PAD;
+    }
+    bitonic_sort_regs_fixed<uint32_t, E, THREADS>(v, sorted);
+    __syncthreads();                                                 // the last LDS stage's reads are done
+    double pt[E][DIM];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        sorted[tid * E + e] = v[e];
+        const double* p = P + (size_t)(v[e] == PAD ? 0u : (v[e] & row_mask)) * DIM;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) pt[e][d] = p[d];
+    }
+    if (tid == 0) sorted[E * THREADS] = PAD;                         // one slot behind the last element
+    __syncthreads();
+    const uint32_t before = tid > 0 ? sorted[tid * E - 1] : PAD;
+    bool head[E];
+    int nh = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const uint32_t prev = e > 0 ? v[e - 1] : before;
+        head[e] = v[e] != PAD && ((tid == 0 && e == 0) || (prev >> row_bits) != (v[e] >> row_bits));
+        nh += head[e] ? 1 : 0;
+    }
+    int total;
+    int vid = block_exscan(nh, iscratch, total);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if (!head[e]) continue;
+        const uint32_t key = v[e] >> row_bits;
+        double s[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) s[d] = 0.0 + pt[e][d];         // np.bincount starts from zero
+        int c = 1;
+        bool open = true;                                            // the run has not met another key yet
+#pragma unroll
+        for (int f = e + 1; f < E; ++f) {
+            open = open && v[f] != PAD && (v[f] >> row_bits) == key;
+            if (open) {
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) s[d] += pt[f][d];
+                ++c;
+            }
+        }
+        if (open) {                                                  // past the thread's own elements (the slot behind the array ends it)
+            for (int q = tid * E + E; ; ++q) {
+                const uint32_t w = sorted[q];
+                if (w == PAD || (w >> row_bits) != key) break;
+                const double* p = P + (size_t)(w & row_mask) * DIM;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) s[d] += p[d];
+                ++c;
+            }
+        }
+        const double cd = (double)c;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) O[(size_t)vid * DIM + d] = s[d] / cd;
+        ++vid;
+    }
+    if (tid == 0) *out_cnt = total;
+}
+
 // ── small path: one workgroup per cloud, everything in LDS ─────────────────
 template <int DIM>
 __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
@@ -167,6 +258,17 @@ __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
 #pragma unroll
     for (int d = 0; d < DIM; ++d) cells *= ext[d];                      // keys are below this product
     const double packed_range = cells * (double)npad;                   // packed values are below this
+    if (VOX_REGS && packed_range < 4.0e9 && (npad == 4 * (int)blockDim.x || npad == 2 * (int)blockDim.x) && (blockDim.x == 512 || blockDim.x == 1024)) {
+        uint32_t* sorted = reinterpret_cast<uint32_t*>(dyn);             // npad + 1 words
+        if (blockDim.x == 512) {
+            if (npad == 2048) voxel_small_regs<DIM, 4, 512>(P, O, n, voxel, mn, ext, row_bits, sorted, iscratch, out_cnt + c);
+            else voxel_small_regs<DIM, 2, 512>(P, O, n, voxel, mn, ext, row_bits, sorted, iscratch, out_cnt + c);
+        } else {
+            if (npad == 4096) voxel_small_regs<DIM, 4, 1024>(P, O, n, voxel, mn, ext, row_bits, sorted, iscratch, out_cnt + c);
+            else voxel_small_regs<DIM, 2, 1024>(P, O, n, voxel, mn, ext, row_bits, sorted, iscratch, out_cnt + c);
+        }
+        return;
+    }
     if (packed_range < 4.0e9) {
         uint32_t* pk = rows;                                             // sorted in the row array, unpacked in place
         if (npad == 4 * (int)blockDim.x || npad == 2 * (int)blockDim.x) {
