@@ -152,19 +152,54 @@ __device__ __forceinline__ uint32_t vox_key32(const double* p, const double (&mn
     return k;
 }
 
+// Returns false (nothing written) when key and row do not fit one 32-bit word: the caller's general path takes over.
 template <int DIM, int E, int THREADS>
-__device__ __forceinline__ void voxel_small_regs(const double* __restrict__ P, double* __restrict__ O, int n, double voxel,
-                                                 const double (&mn)[3], const double (&extd)[3], int row_bits, uint32_t* sorted,
-                                                 int* iscratch, int32_t* out_cnt) {
+__device__ __forceinline__ bool voxel_small_regs(const double* __restrict__ P, double* __restrict__ O, int n, double voxel,
+                                                 uint32_t* sorted, double* dscratch, int* iscratch, int32_t* out_cnt) {
     constexpr uint32_t PAD = 0xffffffffu;
+    constexpr int NW = THREADS / ICPMI_WAVE;
     const int tid = (int)threadIdx.x;
+    // the thread's rows e THREADS + t (coalesced; any start order sorts the same) stay in registers from the bounds to the keys
+    double raw[E][DIM];
+    double mn[3], mx[3], extd[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { mn[d] = __builtin_inf(); mx[d] = -__builtin_inf(); }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * THREADS + tid;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+            raw[e][d] = i < n ? P[(size_t)i * DIM + d] : 0.0;
+            if (i < n) { mn[d] = fmin(mn[d], raw[e][d]); mx[d] = fmax(mx[d], raw[e][d]); }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) { mn[d] = wave_min(mn[d]); mx[d] = wave_max(mx[d]); }
+    if (lane_id() == 0)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) { dscratch[d * VOX_MAXW + wave_id()] = mn[d]; dscratch[(3 + d) * VOX_MAXW + wave_id()] = mx[d]; }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+        double a = __builtin_inf(), b = -__builtin_inf();
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { a = fmin(a, dscratch[d * VOX_MAXW + k]); b = fmax(b, dscratch[(3 + d) * VOX_MAXW + k]); }
+        mn[d] = a; mx[d] = b;
+    }
+    if (!key_extents<DIM>(mn, mx, voxel, extd)) { if (tid == 0) *out_cnt = -1; return true; }
+    int row_bits = 6;
+    while ((1 << row_bits) < E * THREADS) ++row_bits;
+    double cells = 1.0;
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) cells *= extd[d];
+    if (!(cells * (double)(E * THREADS) < 4.0e9)) return false;     // (uniform: every thread holds the same bounds)
     const uint32_t ext[3] = {(uint32_t)extd[0], (uint32_t)extd[1], (uint32_t)extd[2]};
     const uint32_t row_mask = (1u << row_bits) - 1u;
     uint32_t v[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {                                    // rows e THREADS + t: coalesced; any start order sorts the same
+    for (int e = 0; e < E; ++e) {
         const int i = e * THREADS + tid;
-        v[e] = i < n ? (vox_key32<DIM>(P + (size_t)i * DIM, mn, ext, voxel) << row_bits) | (uint32_t)i : PAD;
+        v[e] = i < n ? (vox_key32<DIM>(raw[e], mn, ext, voxel) << row_bits) | (uint32_t)i : PAD;
     }
     bitonic_sort_regs_fixed<uint32_t, E, THREADS>(v, sorted);
     __syncthreads();                                                 // the last LDS stage's reads are done
@@ -223,6 +258,7 @@ __device__ __forceinline__ void voxel_small_regs(const double* __restrict__ P, d
         ++vid;
     }
     if (tid == 0) *out_cnt = total;
+    return true;
 }
 
 // ── small path: one workgroup per cloud, everything in LDS ─────────────────
@@ -244,6 +280,19 @@ __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
     uint64_t* keys = reinterpret_cast<uint64_t*>(dyn);
     uint32_t* rows = reinterpret_cast<uint32_t*>(dyn + (size_t)npad * sizeof(uint64_t));
 
+    if (VOX_REGS && VOX_STOP_AFTER == 0 && (npad == 4 * (int)blockDim.x || npad == 2 * (int)blockDim.x) && (blockDim.x == 512 || blockDim.x == 1024)) {
+        uint32_t* sorted = reinterpret_cast<uint32_t*>(dyn);             // npad + 1 words
+        bool done;
+        if (blockDim.x == 512) {
+            if (npad == 2048) done = voxel_small_regs<DIM, 4, 512>(P, O, n, voxel, sorted, dscratch, iscratch, out_cnt + c);
+            else done = voxel_small_regs<DIM, 2, 512>(P, O, n, voxel, sorted, dscratch, iscratch, out_cnt + c);
+        } else {
+            if (npad == 4096) done = voxel_small_regs<DIM, 4, 1024>(P, O, n, voxel, sorted, dscratch, iscratch, out_cnt + c);
+            else done = voxel_small_regs<DIM, 2, 1024>(P, O, n, voxel, sorted, dscratch, iscratch, out_cnt + c);
+        }
+        if (done) return;
+        __syncthreads();                                                 // dscratch is written again below
+    }
     double mn[3], mx[3], ext[3];
     cloud_bounds<DIM>(P, n, mn, mx, dscratch);
 #if VOX_STOP_AFTER == 1
@@ -258,17 +307,6 @@ __global__ __launch_bounds__(VOX_THREADS) void voxel_small_kernel(
 #pragma unroll
     for (int d = 0; d < DIM; ++d) cells *= ext[d];                      // keys are below this product
     const double packed_range = cells * (double)npad;                   // packed values are below this
-    if (VOX_REGS && packed_range < 4.0e9 && (npad == 4 * (int)blockDim.x || npad == 2 * (int)blockDim.x) && (blockDim.x == 512 || blockDim.x == 1024)) {
-        uint32_t* sorted = reinterpret_cast<uint32_t*>(dyn);             // npad + 1 words
-        if (blockDim.x == 512) {
-            if (npad == 2048) voxel_small_regs<DIM, 4, 512>(P, O, n, voxel, mn, ext, row_bits, sorted, iscratch, out_cnt + c);
-            else voxel_small_regs<DIM, 2, 512>(P, O, n, voxel, mn, ext, row_bits, sorted, iscratch, out_cnt + c);
-        } else {
-            if (npad == 4096) voxel_small_regs<DIM, 4, 1024>(P, O, n, voxel, mn, ext, row_bits, sorted, iscratch, out_cnt + c);
-            else voxel_small_regs<DIM, 2, 1024>(P, O, n, voxel, mn, ext, row_bits, sorted, iscratch, out_cnt + c);
-        }
-        return;
-    }
     if (packed_range < 4.0e9) {
         uint32_t* pk = rows;                                             // sorted in the row array, unpacked in place
         if (npad == 4 * (int)blockDim.x || npad == 2 * (int)blockDim.x) {
