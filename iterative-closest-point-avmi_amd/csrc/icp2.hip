@@ -154,6 +154,9 @@ constexpr int CTRL_RT = 12, CTRL_TT = 16, CTRL_ERR = 18, CTRL_PREV = 19, CTRL_DE
 #ifndef ICP2_PK
 #define ICP2_PK 1               // searches of the filter instantiations by the packed float32 walk (sweep.hpp, round 4); 0: the round-2 walks
 #endif
+#ifndef ICP2_FAR_PK
+#define ICP2_FAR_PK 1           // the far continuation's searches by the packed walk and scan (sweep.hpp, round 4)
+#endif
 #ifndef ICP2_STAGE1_ITERS
 #define ICP2_STAGE1_ITERS 12    // iterations of the first stage of a large batch (launch_icp2)
 #endif
@@ -502,6 +505,8 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                         const FarSlot e = far_q[j];
 #ifdef ICPMI_DIAG
                         const Top2 r = sweepf_top2_far(lds_sq, sxy, lds_tree, tree_leaves, filt, M, dir, uabs, e.in.x, e.in.y, e.in.seed, &res[11]);
+#elif ICP2_FAR_PK
+                        const Top2 r = sweepf_top2_far_pk(lds_sq, sxy, lds_tree, tree_leaves, filt, M, dir, uabs, e.in.x, e.in.y, e.in.seed);
 #else
                         const Top2 r = sweepf_top2_far(lds_sq, sxy, lds_tree, tree_leaves, filt, M, dir, uabs, e.in.x, e.in.y, e.in.seed);
 #endif

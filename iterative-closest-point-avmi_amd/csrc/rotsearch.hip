@@ -362,6 +362,9 @@ typedef float rsb_v2f __attribute__((ext_vector_type(2)));
 
 // rounds of a row's walk before the box hierarchy takes over (sweep.hpp: sweepf_nn_far): most coarse angles the bounds
 // cannot exclude put the rows decimetres to metres off, the fine grid lies about the winner
+#ifndef RSB_PK
+#define RSB_PK 1                // the rows' searches by the packed float32 walk / scan (sweep.hpp, round 4); 0: the round-3 searches
+#endif
 #ifndef RSB_COARSE_ROUNDS
 #define RSB_COARSE_ROUNDS 6
 #endif
@@ -383,7 +386,11 @@ __device__ __forceinline__ double rsb_score_angle(const double2* src_c, int n, c
             const double2 p = src_c[i];
             const double qx = (p.x * c + p.y * -s) + shx, qy = (p.x * s + p.y * c) + shy;   // src_c @ R.T + mu_t, features.py:216
             double d2;
+#if RSB_PK
+            (void)sweepf_nn_far_pk(sq, sxy, tree, leaves, filt, m, dir, uabs, qx, qy, d2, walk_rounds);
+#else
             (void)sweepf_nn_far(sq, sxy, tree, leaves, filt, m, dir, uabs, qx, qy, d2, walk_rounds);
+#endif
             const double d = sqrt(d2);                                  // KDTree distance ...
             acc += d * d;                                               // ... squared, features.py:218
         }
