@@ -155,7 +155,10 @@ constexpr int CTRL_RT = 12, CTRL_TT = 16, CTRL_ERR = 18, CTRL_PREV = 19, CTRL_DE
 #define ICP2_PK 1               // searches of the filter instantiations by the packed float32 walk (sweep.hpp, round 4); 0: the round-2 walks
 #endif
 #ifndef ICP2_FAR_PK
-#define ICP2_FAR_PK 1           // the far continuation's searches by the packed walk and scan (sweep.hpp, round 4)
+#define ICP2_FAR_PK 0           // 1: the far continuation's searches by the packed walk and scan too (sweep.hpp) — exact (its tests pass on it) and
+                                // slower there: 4.05 against 3.74 ms for the ICP half of the 3 m / 20 degree candidates.  The continuation has already
+                                // packed its searching rows into few lanes, and a scan that offers every image of a block it enters issues more than
+                                // one that evaluates the few images inside the threshold exactly.
 #endif
 #ifndef ICP2_STAGE1_ITERS
 #define ICP2_STAGE1_ITERS 12    // iterations of the first stage of a large batch (launch_icp2)

@@ -1016,12 +1016,13 @@ __device__ __forceinline__ int sweepf_nn_far(const float4* sq, const double2* sx
 
 // ── far queries by the packed walk and a packed scan of the box hierarchy (round 4) ──────────────────
 // As in the packed walks: nothing but float32 until the list is complete.  The scan offers every image of a block it
-// enters (a select, no branch) and prunes subtrees against T(B) of the list's bounding entry; positions the walk has
-// taken are met again and offered a second time — identical words, dropped when the list is read (a word can occur at
-// most twice, so a list of K + 1 entries still holds K distinct ones).
+// enters (a select, no branch) and prunes subtrees against T(B) of the list's bounding entry.
+// T0: a threshold known beforehand (from the candidates a walk has met; NaN: none) — the scan's own list may start empty
 template <int K, int NB>
-__device__ __forceinline__ void sweep_pk_far_scan(const float4* sq, const float4* tree, int leaves, int m, const SweepPkQuery& fq, SweepPkList<K>& L) {
-    float T = fq.threshold(fq.dist_bound(L.m[NB]));                    // NaN while the list is short: nothing is pruned
+__device__ __forceinline__ void sweep_pk_far_scan(const float4* sq, const float4* tree, int leaves, int m, const SweepPkQuery& fq, SweepPkList<K>& L,
+                                                  float T0 = __builtin_nanf("")) {
+    auto tighter = [](float a, float b) { return (a != a || b < a) ? (b != b ? a : b) : a; };    // the smaller of two thresholds, NaN = none
+    float T = tighter(T0, fq.threshold(fq.dist_bound(L.m[NB])));       // NaN while nothing bounds: nothing is pruned
     int node = 1;
     unsigned trail = 0;
     bool tested = true;                                                // the root is entered untested
@@ -1054,7 +1055,7 @@ __device__ __forceinline__ void sweep_pk_far_scan(const float4* sq, const float4
 #pragma unroll
                 for (int k = 0; k < 8; ++k) L.offer(sweep_pk(v[k], i0 + k, i0 + k < m));
             }
-            T = fq.threshold(fq.dist_bound(L.m[NB]));
+            T = tighter(T, fq.threshold(fq.dist_bound(L.m[NB])));
         }
         if (trail == 0) break;
         const int up = __builtin_ctz(trail);
@@ -1064,43 +1065,27 @@ __device__ __forceinline__ void sweep_pk_far_scan(const float4* sq, const float4
     }
 }
 
-// distinct entries of a list that may hold a word twice: d[0 .. ND), NONE-padded
-template <int K, int ND>
-__device__ __forceinline__ void sweep_pk_distinct(const SweepPkList<K>& L, unsigned (&d)[ND]) {
-    // ascending order: equal words are neighbours
-    unsigned prev = SWEEP_PK_NONE;
-    int n = 0;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) d[j] = SWEEP_PK_NONE;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const bool fresh = L.m[k] != SWEEP_PK_NONE && (k == 0 || L.m[k] != prev);
-#pragma unroll
-        for (int j = 0; j < ND; ++j) d[j] = (fresh && n == j) ? L.m[k] : d[j];
-        n += fresh ? 1 : 0;
-        prev = L.m[k];
-    }
-}
-
 // sweepf_nn_far by the packed walk and scan: position of the nearest point and its exact squared distance
 __device__ __forceinline__ int sweepf_nn_far_pk(const float4* sq, const double2* sxy, const float4* tree, int leaves, const SweepF& f, int m, int dir,
                                                 double uabs, double qx, double qy, double& d2_out, int max_rounds = SWEEP_FAR_ROUNDS) {
     const SweepPkQuery fq(f, dir, uabs, qx, qy);
-    SweepPkList<4> L;
+    SweepPkList<3> L;
     const int h0 = sweepf_lower_bound(sq, m, fq.u);
-    const bool done = fq.polar ? sweep_pk_walk<4, 0, true>(sq, fq, h0 - 1, h0, m, -1, L, max_rounds)
-                               : sweep_pk_walk<4, 0, false>(sq, fq, h0 - 1, h0, m, -1, L, max_rounds);
-    if (!done) sweep_pk_far_scan<4, 0>(sq, tree, leaves, m, fq, L);
-    unsigned d[3];
-    sweep_pk_distinct<4, 3>(L, d);
-    const float T = fq.threshold(fq.dist_bound(d[0]));
-    const bool a2 = d[1] != SWEEP_PK_NONE && !(sweep_pk_floor(d[1]) > T);
-    const bool a3 = d[2] != SWEEP_PK_NONE && !(sweep_pk_floor(d[2]) > T);
-    if (a3 || fq.bad || d[0] == SWEEP_PK_NONE) return sweepf_nn_far(sq, sxy, tree, leaves, f, m, dir, uabs, qx, qy, d2_out, max_rounds);
-    int bpos = (int)(d[0] & SWEEP_PK_IDX);
+    const bool done = fq.polar ? sweep_pk_walk<3, 0, true>(sq, fq, h0 - 1, h0, m, -1, L, max_rounds)
+                               : sweep_pk_walk<3, 0, false>(sq, fq, h0 - 1, h0, m, -1, L, max_rounds);
+    if (!done) {                                                       // the scan's own list (see sweepf_top2_far_pk): no word twice
+        SweepPkList<3> S;
+        sweep_pk_far_scan<3, 0>(sq, tree, leaves, m, fq, S, fq.threshold(fq.dist_bound(L.m[0])));
+        L = S;
+    }
+    const float T = fq.threshold(fq.dist_bound(L.m[0]));
+    const bool a2 = L.m[1] != SWEEP_PK_NONE && !(sweep_pk_floor(L.m[1]) > T);
+    const bool a3 = L.m[2] != SWEEP_PK_NONE && !(sweep_pk_floor(L.m[2]) > T);
+    if (a3 || fq.bad || L.m[0] == SWEEP_PK_NONE) return sweepf_nn_far(sq, sxy, tree, leaves, f, m, dir, uabs, qx, qy, d2_out, max_rounds);
+    int bpos = (int)(L.m[0] & SWEEP_PK_IDX);
     double best = sweep_d2(qx, qy, sxy[bpos]);
     if (a2) {                                                          // two candidates within the filter's resolution: exact, rows on a tie
-        const int i2 = (int)(d[1] & SWEEP_PK_IDX);
+        const int i2 = (int)(L.m[1] & SWEEP_PK_IDX);
         const double s2 = sweep_d2(qx, qy, sxy[i2]);
         if (s2 < best || (s2 == best && sweepf_row(sq[i2]) < sweepf_row(sq[bpos]))) { bpos = i2; best = s2; }
     }
@@ -1188,23 +1173,27 @@ __device__ __forceinline__ Top2 sweepf_top2_far(const float4* sq, const double2*
     return t;
 }
 
-// sweepf_top2_far by the packed walk and scan (the far continuation's searches)
+// sweepf_top2_far by the packed walk and scan (the far continuation's searches).  A word offered twice would stand for two
+// of the three nearest and bound the window by the SECOND distance: so the scan keeps a list of its own — everything
+// the walk has met within its bound is met again, the walk only lends its threshold.
 __device__ __forceinline__ Top2 sweepf_top2_far_pk(const float4* sq, const double2* sxy, const float4* tree, int leaves, const SweepF& f, int m, int dir,
                                                    double uabs, double qx, double qy, int seed) {
     const SweepPkQuery fq(f, dir, uabs, qx, qy);
-    SweepPkList<5> L;
+    SweepPkList<4> L;
     const bool seeded = seed >= 0 && seed < m;
     const bool from_seed = seeded && !(fq.polar && fabsf(sq[seed].z - fq.u) > 3.0f);
     const int h0 = from_seed ? seed + 1 : sweepf_lower_bound(sq, m, fq.u);
-    const bool done = fq.polar ? sweep_pk_walk<5, 2, true>(sq, fq, h0 - 1, h0, m, -1, L, SWEEP_FAR_ROUNDS_TOP2)
-                               : sweep_pk_walk<5, 2, false>(sq, fq, h0 - 1, h0, m, -1, L, SWEEP_FAR_ROUNDS_TOP2);
-    if (!done) sweep_pk_far_scan<5, 2>(sq, tree, leaves, m, fq, L);
-    unsigned d[4];
-    sweep_pk_distinct<5, 4>(L, d);
-    const float T = fq.threshold(fq.dist_bound(d[2]));
-    const bool a4 = d[3] != SWEEP_PK_NONE && !(sweep_pk_floor(d[3]) > T);
-    if (a4 || fq.bad || d[0] == SWEEP_PK_NONE) return sweepf_top2_far(sq, sxy, tree, leaves, f, m, dir, uabs, qx, qy, seed);
-    return sweep_pk_top2_exact(sq, sxy, qx, qy, d[0], d[1], d[2]);
+    const bool done = fq.polar ? sweep_pk_walk<4, 2, true>(sq, fq, h0 - 1, h0, m, -1, L, SWEEP_FAR_ROUNDS_TOP2)
+                               : sweep_pk_walk<4, 2, false>(sq, fq, h0 - 1, h0, m, -1, L, SWEEP_FAR_ROUNDS_TOP2);
+    if (!done) {
+        SweepPkList<4> S;
+        sweep_pk_far_scan<4, 2>(sq, tree, leaves, m, fq, S, fq.threshold(fq.dist_bound(L.m[2])));
+        L = S;
+    }
+    const float T = fq.threshold(fq.dist_bound(L.m[2]));
+    const bool a4 = L.m[3] != SWEEP_PK_NONE && !(sweep_pk_floor(L.m[3]) > T);
+    if (a4 || fq.bad || L.m[0] == SWEEP_PK_NONE) return sweepf_top2_far(sq, sxy, tree, leaves, f, m, dir, uabs, qx, qy, seed);
+    return sweep_pk_top2_exact(sq, sxy, qx, qy, L.m[0], L.m[1], L.m[2]);
 }
 
 #endif
