@@ -94,6 +94,14 @@ const char* icpmi_strerror(int code);
  * library made (they are made again on demand); call it before unloading. */
 int icpmi_set_option(const char* name, const char* value);
 int icpmi_shutdown(void);
+/* One HIP runtime per process: the streams and device pointers a caller hands over must belong to the runtime the
+ * library's launches go through.  A process that maps TWO copies of libamdhip64 (this library's /opt/rocm one, loaded
+ * first, and the copy PyTorch bundles, loaded later — or the other way round without the loader finding the first)
+ * fails every launch with ICPMI_ERR_HIP and nothing to tell why.  icpmi_runtime_check walks the loaded objects
+ * (dl_iterate_phdr): ICPMI_OK when at most one libamdhip64 is mapped, else ICPMI_ERR_HIP with the paths written to
+ * msg (NUL-terminated, at most msg_bytes; msg may be NULL).  The reference has no counterpart (pure Python); the
+ * Python host layer (icpmi/_lib.py) calls it right after loading the library and whenever a call returns ICPMI_ERR_HIP. */
+int icpmi_runtime_check(char* msg, size_t msg_bytes);
 
 /* ---- voxel_downsample, utilities/icp.py:117-129 --------------------------
  * For every cloud c: keys floor((p - min_c) / voxel) per axis, lexicographic

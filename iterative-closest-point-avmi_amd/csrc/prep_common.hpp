@@ -7,6 +7,9 @@
 namespace icpmi {
 
 constexpr int PREP_BINS = 64;
+#ifndef PREP_ABLATE
+#define PREP_ABLATE 0           // diagnostic variants only (wrong results): 1 no walk, 2 no normal, 3 neither network nor walk nor normal
+#endif
 
 // Search axis of a cloud: ranges of the four projections x, y, x+y, x-y, a 64-bin histogram per axis, and
 // the axis with the smallest expected search window (sum of squared bin counts / bin width; the diagonals
@@ -289,9 +292,10 @@ __device__ __forceinline__ void prep_normals_polar(const double2* sxy, const int
         int lo, hi, remaining;                                       // remaining: positions not yet looked at
         if (M >= KK) {
             const int b0 = min(max(s - KK / 2, 0), M - KK);
-            top.init_block(sxy, sorig, b0, q);
+            if (PREP_ABLATE == 3) { top.init(); top.template load_from<0>(sxy, b0, q); }     // distances only: no network
+            else top.init_block(sxy, sorig, b0, q);
             window(kk == KK ? top.d[KK - 1] : top.kth(kk - 1));
-            lo = b0 - 1; hi = b0 + KK; remaining = M - KK;
+            lo = b0 - 1; hi = b0 + KK; remaining = PREP_ABLATE == 3 ? 0 : M - KK;
         } else {
             top.init();
             top.push(0.0, s, sorig);
@@ -303,7 +307,7 @@ __device__ __forceinline__ void prep_normals_polar(const double2* sxy, const int
         float offr = 0.0f, offl = 0.0f;
         if (hi >= M) { hi -= M; offr = 6.2831855f; }
         if (lo < 0) { lo += M; offl = 6.2831855f; }
-        bool openr = true, openl = true;
+        bool openr = PREP_ABLATE != 1, openl = PREP_ABLATE != 1;          // (PREP_ABLATE: diagnostic variants only — 1 no walk, 2 no normal)
         // one candidate from each open side per round; bearings and points of both are loaded before either is used and
         // the next pair is fetched meanwhile
         float tr = sth[hi], tl = sth[lo];
@@ -325,6 +329,8 @@ __device__ __forceinline__ void prep_normals_polar(const double2* sxy, const int
             if (inr) { if (nh == 0) offr = 6.2831855f; hi = nh; tr = ntr; cr = ncr; }
             if (inl) { if (lo == 0) offl = 6.2831855f; lo = nl; tl = ntl; cl = ncl; }
         }
+        if (PREP_ABLATE == 2) { out_sorted[s] = make_double2(top.d[KK - 1], (double)top.p[0]); continue; }
+        if (PREP_ABLATE == 3) { out_sorted[s] = make_double2((double)hi, (double)lo); continue; }
         emit_normal<KK>(top, kk, sxy, sorig, s, out_sorted, out_rows);
     }
 }

@@ -16,9 +16,13 @@
 //    this is a mirror of what was set, nothing to destroy.
 //
 // Nothing else in the library outlives a call: no allocations, no handles.
+#include <link.h>
+
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 
@@ -116,6 +120,25 @@ extern "C" int icpmi_set_option(const char* name, const char* value) {
     o.load();
     if (value) o.values[n] = value; else o.values.erase(n);
     return ICPMI_OK;
+}
+
+static int count_hip_runtimes(struct dl_phdr_info* info, size_t, void* data) {
+    if (info->dlpi_name && strstr(info->dlpi_name, "libamdhip64")) static_cast<std::set<std::string>*>(data)->insert(info->dlpi_name);
+    return 0;
+}
+
+extern "C" int icpmi_runtime_check(char* msg, size_t msg_bytes) {
+    std::set<std::string> seen;
+    dl_iterate_phdr(count_hip_runtimes, &seen);
+    if (msg && msg_bytes) msg[0] = 0;
+    if (seen.size() <= 1) return ICPMI_OK;
+    if (msg && msg_bytes) {
+        std::string m = "two HIP runtimes in one process:";
+        for (const std::string& p : seen) m += " " + p;
+        m += " - load the framework that brings its own (import torch) BEFORE libicpmi.so";
+        snprintf(msg, msg_bytes, "%s", m.c_str());
+    }
+    return ICPMI_ERR_HIP;
 }
 
 extern "C" int icpmi_shutdown(void) {

@@ -44,6 +44,7 @@ _SIGS = {
     "icpmi_strerror": (C.c_char_p, [C.c_int]),
     "icpmi_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
     "icpmi_shutdown": (C.c_int, []),
+    "icpmi_runtime_check": (C.c_int, [C.c_char_p, C.c_size_t]),
     "icpmi_voxel_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "icpmi_voxel_downsample_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_double,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -119,12 +120,28 @@ def lib():
             f = getattr(L, name)          # AttributeError here means the .so is stale
             f.restype, f.argtypes = res, args
         _lib = L
+        why = runtime_problem()
+        if why:
+            _lib = None
+            raise IcpmiError(why)
     return _lib
+
+
+def runtime_problem():
+    """'' or what icpmi_runtime_check found: two copies of libamdhip64 mapped into this process (every launch would fail)."""
+    if _lib is None:
+        return ""
+    buf = C.create_string_buffer(1024)
+    return buf.value.decode() if _lib.icpmi_runtime_check(buf, len(buf)) != OK else ""
+
+
+ERR_HIP = -3
 
 
 def check(code, what):
     if code != OK:
-        raise IcpmiError(f"{what}: {lib().icpmi_strerror(code).decode()} ({code})")
+        hint = runtime_problem() if code == ERR_HIP else ""
+        raise IcpmiError(f"{what}: {lib().icpmi_strerror(code).decode()} ({code})" + (f" [{hint}]" if hint else ""))
 
 
 def set_option(name, value):

@@ -25,7 +25,8 @@ def test_library_builds_and_exports_header_symbols():
     import ctypes
     import icpmi
     path = icpmi.build()
-    L = ctypes.CDLL(path)
+    lib = icpmi.lib()                     # torch first, then the library: ONE HIP runtime in the process (icpmi_runtime_check)
+    L = ctypes.CDLL(path)                 # the same mapping, seen through a plain handle
     syms = declared_symbols()
     assert len(syms) >= 14
     for s in syms:
@@ -33,7 +34,7 @@ def test_library_builds_and_exports_header_symbols():
     # and the Python binding knows every one of them
     from icpmi import _lib
     assert sorted(_lib.EXPORTS) == syms
-    lib = icpmi.lib()
+    assert _lib.runtime_problem() == ""
     assert lib.icpmi_version().decode().startswith("icpmi")
     assert lib.icpmi_strerror(-2).decode() == "workspace missing or too small"
     # host-only size queries (no GPU touched)
@@ -41,6 +42,25 @@ def test_library_builds_and_exports_header_symbols():
     assert lib.icpmi_icp_workspace_bytes(2, 100, 2) == 2 * 100 * (16 + 8 + 4) + 256
     assert lib.icpmi_voxel_workspace_bytes(2048) == 256
     assert lib.icpmi_voxel_workspace_bytes(100000) > 100000 * 24
+
+
+def test_two_hip_runtimes_in_one_process_are_named():
+    """libicpmi.so loaded BEFORE torch maps /opt/rocm's libamdhip64 and torch then maps its own — every
+    launch would fail with a bare ICPMI_ERR_HIP.  icpmi_runtime_check names the two copies; the Python loader raises with
+    that message instead of handing out a library that cannot launch."""
+    code = (f"import ctypes, sys; sys.path.insert(0, {PKG!r}); L = ctypes.CDLL({os.path.join(PKG, 'lib', 'libicpmi.so')!r});"
+            "buf = ctypes.create_string_buffer(1024); L.icpmi_runtime_check.argtypes = [ctypes.c_char_p, ctypes.c_size_t];"
+            "assert L.icpmi_runtime_check(buf, 1024) == 0, buf.value;"          # the library alone: one runtime
+            "import torch;"
+            "rc = L.icpmi_runtime_check(buf, 1024); print('RC', rc, buf.value.decode());"
+            "from icpmi import _lib\n"
+            "try:\n    _lib.lib(); print('LOADED')\nexcept _lib.IcpmiError as e:\n    print('RAISED', e)\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    if "RC 0" in r.stdout:                # torch resolved to the runtime already mapped (same SONAME): nothing to diagnose
+        assert "LOADED" in r.stdout
+    else:
+        assert "RC -3 two HIP runtimes in one process" in r.stdout and "RAISED two HIP runtimes" in r.stdout, r.stdout
 
 
 def test_struct_layout_matches_header():
