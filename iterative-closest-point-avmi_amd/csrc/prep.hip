@@ -9,6 +9,9 @@
 
 namespace icpmi {
 
+#ifndef PREP_AXIS_STEP
+#define PREP_AXIS_STEP 4        // large batches estimate the search axis on every PREP_AXIS_STEP-th point
+#endif
 #ifndef ICPMI_PREP_WPS
 #define ICPMI_PREP_WPS 6      // waves per SIMD the k-NN kernel is compiled for up to KK = 13: three workgroups per CU
 #endif
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(PREP_THREADS, (KK <= 13 ? ICPMI_PREP_WPS : (KK <= 1
     uint32_t* rows = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(keys) + (size_t)nsort * 8); // their rows
 
     double bounds[4];
-    const int dir = choose_axis<PREP_THREADS>(P, M, dsc, hist, bounds, polar, (!GRID && M >= 512) ? 4 : 1);   // bounds: the grid's
+    const int dir = choose_axis<PREP_THREADS>(P, M, dsc, hist, bounds, polar, (!GRID && M >= 512) ? PREP_AXIS_STEP : 1);   // bounds: the grid's
     // ── sort along the chosen axis (or by bearing) ───────────────────────────
     if (reg_sort) {
         // (key, row) as ONE 64-bit element: the key's low 11 bits give way to the row, the network runs on registers

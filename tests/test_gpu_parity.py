@@ -1640,3 +1640,33 @@ def test_rotation_search_batch_pair_with_an_unlisted_target(uicp):
     srch.run()
     rec = srch.records.cpu().numpy()
     assert int(rec[0, 11]) == 0 and int(rec[1, 11]) == 2
+
+
+@pytest.mark.parametrize("method", ["point_to_point", "point_to_line"])
+def test_packed_walks_on_exact_ties_and_lattices(uicp, method):
+    """The packed float32 walks (sweep.hpp, round 4) list at most K candidates; exact ties — a source row on the bisector of
+    two lattice points, at the centre of four, near-duplicates — put more candidates within the filter's resolution than
+    the list holds and send the lane to the exact walk, where the (distance, row) rule decides.  Fused path = exhaustive
+    kernel = oracle, iterations included; target rows shuffled so that the row rule is not the sort order."""
+    from icpmi import batch
+    gx, gy = np.meshgrid(np.arange(-16, 17) * 0.25, np.arange(-12, 13) * 0.25)
+    lat = np.stack([gx.ravel(), gy.ravel()], 1)                       # exactly representable lattice
+    rng = np.random.default_rng(5)
+    tgt = lat[rng.permutation(len(lat))]
+    inner = lat[(np.abs(lat[:, 0]) < 3.5) & (np.abs(lat[:, 1]) < 2.5)]
+    th = np.deg2rad(0.7)
+    Rs = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    near = rng.uniform(-3, 3, size=(300, 2))
+    near_dup = np.vstack([near, near + 1e-6, near - 2e-6])                       # three points within microns of each other (distinct voxels at 2^-21):
+                                                                                 # apart in float32, together in the 13 bits a packed word keeps
+    cases = [("half", inner + [0.125, 0.0], tgt, 0.01), ("quarter", inner + [0.125, 0.125], tgt, 0.01),
+             ("rotated", (inner + [0.125, 0.0]) @ Rs.T, tgt, 0.01), ("near_dup", near[:200] + [0.01, -0.02], near_dup, 2.0 ** -21)]
+    for name, s, t, vox in cases:
+        Ro, to, eo, io = oracle.icp(s, t, 1e-12, 25, vox, method=method, normal_k=8)
+        for ex in (False, True):
+            R, tt, err, info = batch.icp_batch([s], [t], 1e-12, 25, vox, None, None, method, 8, force_exhaustive=ex)
+            assert int(info["iters"][0]) == io["iters"] and int(info["status"][0]) == io["status"], (name, ex, info, io)
+            assert rot_err(R[0], tt[0], Ro, to) < FRO_TOL, (name, ex)
+        # a batch of the same pair 80 times: the packed walk is taken when >= 16 lanes of a wave search — they all do here
+        R, tt, err, info = batch.icp_batch([s] * 80, [t] * 80, 1e-12, 25, vox, None, None, method, 8)
+        assert (info["iters"] == io["iters"]).all() and max(rot_err(R[i], tt[i], Ro, to) for i in range(80)) < FRO_TOL, name
