@@ -9,6 +9,9 @@
 
 namespace icpmi {
 
+#ifndef PREP_POLAR32
+#define PREP_POLAR32 1          // bearing order by a 32-bit (fixed-point float32 bearing | row) sort; 0: float64 atan2, 64-bit network
+#endif
 #ifndef PREP_AXIS_STEP
 #define PREP_AXIS_STEP 4        // large batches estimate the search axis on every PREP_AXIS_STEP-th point
 #endif
@@ -22,9 +25,45 @@ constexpr int PREP_MAX_POINTS = 4096;   // sorted copy (20 B/pt) + sort scratch 
 // KK = capacity of the per-query neighbour list (0: no normals); GRID: k-NN through a grid instead of the sweep
 // Sort of up to E * PREP_THREADS rows by (key, row) on registers; leaves keys[i] / rows[i] = full sortable key and row of
 // the i-th smallest, like bitonic_sort_pairs.  by_row, keys: E * PREP_THREADS slots of LDS each; rows: as many.
+// Bearing order (round 4): the key is the float32 bearing in 21 bits of fixed point (steps of 2 pi / 2^21 = 3.0e-6 rad)
+// with the row below it — ONE 32-bit word per point, the network of the voxel filter instead of the 64-bit one, atan2f
+// instead of the float64 atan2 (2.02 -> see DESIGN section 6).  Any order of the points is a correct order for the exact
+// searches; what they need is (a) images that do not decrease along the sorted array — the image IS the quantised key —
+// and (b) every image within the searches' key slack of the true bearing: the floor 3.0e-6 + the float32 product in
+// front of it (up to an eighth of a step at 2^21) + atan2f and its float32 inputs ~1e-6 + the image's own two roundings
+// 7e-7 < 5.3e-6 (SweepFQuery::mu = 1e-5 with the query's own atan2f and the subtraction; the normals' walk compares two
+// images: 1.6e-5).  Equal keys keep row order; no fix-up.
+constexpr float PREP_POLAR_Q = 6.283185307179586f / 2097152.0f;        // 2 pi / 2^21
+__device__ __forceinline__ uint32_t prep_polar_key21(double x, double y) {
+    const float t = (atan2f((float)y, (float)x) + 3.14159265f) * (2097152.0f / 6.283185307179586f);
+    const int k = (int)t;
+    return (uint32_t)(k < 0 ? 0 : (k > 2097151 ? 2097151 : k));        // NaN -> 0: any key is a correct key
+}
+__device__ __forceinline__ float prep_polar_image(uint32_t k21) { return (float)k21 * PREP_POLAR_Q - 3.14159265f; }
+
+template <int E>
+__device__ __forceinline__ void prep_sort_polar32(const double* __restrict__ P, int M, uint64_t* keys, uint32_t* rows) {
+    uint32_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = e * PREP_THREADS + (int)threadIdx.x;            // coalesced; any start order sorts the same
+        v[e] = i < M ? (prep_polar_key21(P[2 * i], P[2 * i + 1]) << 11) | (uint32_t)i : 0xffffffffu;
+    }
+    bitonic_sort_regs_fixed<uint32_t, E, PREP_THREADS>(v, reinterpret_cast<uint32_t*>(keys));
+    __syncthreads();                                                   // the network's scratch is the key array written next
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = (int)threadIdx.x * E + e;
+        rows[i] = v[e] == 0xffffffffu ? 0xffffffffu : (v[e] & 0x7ffu);
+        keys[i] = v[e] == 0xffffffffu ? ~0ull : f64_sortable((double)prep_polar_image(v[e] >> 11));   // the image is the key from here on
+    }
+    __syncthreads();
+}
+
 template <int E>
 __device__ __forceinline__ void prep_sort_regs(const double* __restrict__ P, int M, int dir, uint64_t* by_row, uint64_t* keys,
                                                uint32_t* rows) {
+    if (PREP_POLAR32 && dir == SWEEP_POLAR) { prep_sort_polar32<E>(P, M, keys, rows); return; }
     constexpr uint64_t ROW_MASK = 0x7ff;                               // rows below 2 048
     uint64_t v[E];
 #pragma unroll

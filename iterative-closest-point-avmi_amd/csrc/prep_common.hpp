@@ -287,7 +287,7 @@ __device__ __forceinline__ void prep_normals_polar(const double2* sxy, const int
         float W = __builtin_inff();
         auto window = [&](double kth) {
             const float t = (__builtin_amdgcn_sqrtf((float)kth) * 1.000001f + 1e-18f) * kw;
-            W = t <= 0.7f ? (t + 0.3f * t * t * t) * 1.000001f + 1e-6f : __builtin_inff();      // asin t <= t + 0.3 t^3 on [0, 0.7]
+            W = t <= 0.7f ? (t + 0.3f * t * t * t) * 1.000001f + 1.6e-5f : __builtin_inff();    // asin t <= t + 0.3 t^3 on [0, 0.7]; two images, each within 5.3e-6 of its bearing (prep.hip)
         };
         int lo, hi, remaining;                                       // remaining: positions not yet looked at
         if (M >= KK) {

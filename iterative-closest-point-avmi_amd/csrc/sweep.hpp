@@ -455,8 +455,9 @@ struct SweepFQuery {
         e15 = 1.8e-7f * (fabsf(x) + fabsf(y) + 2.0f * f.rt) + 1e-30f;
         if (polar) {
             u = atan2f(y, x);
-            // images: fl32 of the float64 bearing (2e-7); here: atan2f of the rounded coordinates (1e-7 + its own few ulp)
-            mu = 4e-6f;
+            // images: the float32 bearing quantised to 2 pi / 2^21 (prep.hip: within 5.3e-6 of the true bearing); here: atan2f
+            // of the rounded coordinates (1e-7 + its own few ulp) and the float32 subtraction of the two: < 7e-6 in all
+            mu = 1e-5f;
             kw = 1.00001f / __builtin_amdgcn_sqrtf(x * x + y * y);       // >= 1 / |q| (inf at the origin: no wedge)
         } else {
             const SweepAxis ax(dir, qx, qy, uabs);
