@@ -194,6 +194,13 @@ def test_bearing_order_gives_identical_results(uicp, libopt):
               (rng.uniform(-2, 2, (900, 2)), rng.uniform(-2, 2, (1100, 2))),               # points all around and near the origin
               (lattice + 0.013, lattice), (seam + [0.02, 0.01], np.vstack([seam, seam[::7] + [2.0, 0.0]])),
               (np.repeat(rng.uniform(-1, 1, (60, 2)), 4, axis=0), np.repeat(rng.uniform(-1, 1, (70, 2)), 3, axis=0))]
+    # round 4: the bearing key is a 21-bit fixed-point float32 bearing — many points per key step: walls seen edge-on
+    # (spokes through the origin: one bearing, many ranges), a cloud 20 km away (its whole extent within a few steps),
+    # a dense arc (neighbours closer than a step)
+    rr = np.linspace(0.5, 6.0, 500)
+    spokes = np.vstack([np.column_stack([rr * np.cos(a), rr * np.sin(a)]) for a in (0.3, 0.3 + 2e-6, -2.9, np.pi)])
+    arc = 4.0 * np.column_stack([np.cos(np.linspace(1.0, 1.002, 1500)), np.sin(np.linspace(1.0, 1.002, 1500))]) + rng.normal(scale=0.05, size=(1500, 2))
+    pairs += [(spokes[::2] + [0.03, 0.02], spokes), (tgts[1] + [2.0e4, -1.5e4], tgts[1] + [2.0e4, -1.5e4] + [0.05, 0.02]), (arc[::3] + 0.02, arc)]
     for method, extra in (("point_to_line", dict(normal_k=12)), ("point_to_point", dict(max_corr_dist=1.5))):
         got = {}
         for mode in ("0", "2", None):
@@ -207,7 +214,7 @@ def test_bearing_order_gives_identical_results(uicp, libopt):
         assert np.array_equal(got["0"], got["2"]), method
         assert np.array_equal(got["0"], got[None]), method
         assert (got["0"][:, 14] >= 2).all()
-    for pts in (tgts[0], tgts[0] + far, rng.uniform(-2, 2, (1100, 2)), lattice, seam):
+    for pts in (tgts[0], tgts[0] + far, rng.uniform(-2, 2, (1100, 2)), lattice, seam, spokes, arc, tgts[1] + [2.0e4, -1.5e4]):
         nrm = {}
         for mode in ("0", "2"):
             libopt.setenv("ICPMI_POLAR", mode)
