@@ -540,11 +540,19 @@ __device__ __forceinline__ void icp2_pair(const Icp2Args& a, const int b) {
                         }
                         else t2 = sweep_top2(sxy, sorig, M, dir, uabs, px[s], py[s], pos[s], centred);
                         pos[s] = t2.p1; pos2[s] = t2.p2;
-                        const double d1 = sqrt(t2.s1), d3 = sqrt(t2.s3);
-                        // minus the rounding of the single-precision anchor; rounded down
-                        const double bud = FAR ? d3 - 1e-13 * (d3 + d1) - 1.3e-7 * (fabs(px[s]) + fabs(py[s]))      // (see the test above)
-                                               : (d3 - d1) * 0.4999999995 - 1e-13 * (d3 + d1) - 1.3e-7 * (fabs(px[s]) + fabs(py[s]));
-                        float bf = (float)bud;
+                        float bf;
+                        if constexpr (FAR) {
+                            const double d1 = sqrt(t2.s1), d3 = sqrt(t2.s3);
+                            // minus the rounding of the single-precision anchor; rounded down                  (see the test above)
+                            bf = (float)(d3 - 1e-13 * (d3 + d1) - 1.3e-7 * (fabs(px[s]) + fabs(py[s])));
+                        } else {
+                            // (d3 - d1) / 2 minus the rounding of the single-precision anchor, from float32 roots rounded the safe way —
+                            // d3 down, d1 up (conversion 2^-24, v_sqrt_f32 one ulp: 1.2e-7 in all, 3e-7 taken) —: two float64 roots were a
+                            // tenth of a top-two search; the budget only has to be a lower bound (round 4)
+                            const float r3 = __builtin_amdgcn_sqrtf((float)t2.s3) * 0.9999997f;
+                            const float r1 = __builtin_amdgcn_sqrtf((float)t2.s1) * 1.0000003f + 1e-30f;
+                            bf = (r3 - r1) * 0.4999999f - 1.3e-7f * (fabsf((float)px[s]) + fabsf((float)py[s]));
+                        }
                         bf = bf - fabsf(bf) * 1e-6f;
                         budget[s] = t2.s3 < __builtin_inf() ? bf : __builtin_inff();
                         ax[s] = (float)px[s]; ay[s] = (float)py[s];
