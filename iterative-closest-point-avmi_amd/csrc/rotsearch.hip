@@ -324,7 +324,11 @@ __global__ __launch_bounds__(RSR_THREADS) void rs_refine_finish_kernel(
 //   4. scores angles exactly in order of that bound, with the exact sorted-sweep search (same float64 distances as
 //      the exhaustive scan), keeping the best exact score so far, and stops at the first angle whose BOUND exceeds it:
 //      every angle not scored is provably worse than one that was, so np.argmin over the scored ones (first minimum)
-//      is np.argmin over all — the winner and its score are exact, bit for bit the single-pair chain's arg-min;
+//      is np.argmin over all.  The nearest-neighbour distances are the exact ones; their SUM is taken in this kernel's own
+//      fixed order (a lane per row with stride 64, then a wave tree; the single-pair kernel strides by 256 and NumPy's
+//      mean sums pairwise), so a score agrees with the other two to rounding (1e-13 in the tests) and the arg-min is
+//      theirs unless two angles tie to within that rounding — which the goldens, the 512-pair comparisons and the
+//      symmetric clouds of the tests have not produced, and which no fixture pins;
 //   5. scores the fine grid around the winner (features.py:227-232) the same way and writes the record and, for the
 //      ICP that follows, R_init / t_init (device memory: no host round trip between pre-alignment and ICP).
 // Typically 8-20 of 240 coarse angles are scored exactly, each by searches of ~10 candidates.
